@@ -1,0 +1,142 @@
+/*
+ * rlcontrol_hip.h -- C ABI of librlcontrol_hip.so: the MI355X (gfx950) replacement for the
+ * replay-sampling + actor-critic-update hot path of samuelfneumann/RLControl.
+ *
+ * The reference has no FFI; its boundary is Python duck typing.  Every entry
+ * point below names the reference interface it replaces (file:line under /root/reference) -- these
+ * are the calls a maintainer's ctypes stub binds (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *   - plain C: opaque handle, pointers + sizes, no C++/torch types.
+ *   - every function returns 0 on success, non-zero on failure; rlc_last_error() gives the message
+ *     (the reference raises Python exceptions: AssertionError utils/replaybuffer.py:34,
+ *      ValueError utils/custom_collections.py:110, NotImplementedError agents/base_agent.py:46).
+ *   - a handle is a POPULATION of n_agents independent DDPG agents (seeds / sweep settings --
+ *     the reference's INDEX axis, main.py:111-141) resident on ONE GPU; agent == 0 with
+ *     n_agents == 1 is the reference's one-agent-per-process case.
+ *   - not thread-safe per handle; one HIP stream per handle; all device state owned by the library.
+ *   - host pointers unless the name ends in _dev.
+ *
+ * Parameter blob ("theta", P floats; P from rlc_ddpg_param_count), variable creation order of
+ * agents/network/hydra_ddpg_network.py:100-140, weights W[in][out] row-major:
+ *   W1[S][H1] b1[H1] | Wa2[H1][HA] ba2[HA] Wa3[HA][A] ba3[A] | Wc2[H1+A][HC] bc2[HC] Wc3[HC] bc3[1]
+ * Adam slots are blob-aligned arrays of P floats (unused positions stay 0).
+ */
+#ifndef RLCONTROL_HIP_H
+#define RLCONTROL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rlc_ddpg rlc_ddpg;
+
+/* Mirrors what DDPG_Network_Manager.__init__ / BaseNetwork.__init__ read from Config
+ * (agents/DDPG.py:17-32, agents/network/base_network.py:14-28, hydra_ddpg_network.py:9-17,
+ *  agents/base_agent.py:22-25, utils/config.py:8-21). */
+typedef struct rlc_ddpg_config {
+    int32_t device;          /* HIP device ordinal (one process per GPU: LOCAL_RANK) */
+    int32_t n_agents;        /* independent agents resident on this GPU (>= 1) */
+    int32_t state_dim;       /* config.state_dim */
+    int32_t action_dim;      /* config.action_dim */
+    int32_t shared_l1_dim;   /* config.shared_l1_dim  (jsonfiles/agent/ddpg.json:8) */
+    int32_t actor_l2_dim;    /* config.actor_l2_dim */
+    int32_t critic_l2_dim;   /* config.critic_l2_dim */
+    int32_t batch_size;      /* config.batch_size (reference default 32, utils/config.py:12) */
+    int64_t buffer_size;     /* config.buffer_size: replay capacity PER AGENT (utils/config.py:13) */
+    int32_t clip_state;      /* 1 when config.norm_type != 'none' (hydra_ddpg_network.py:86-87, quirk Q6) */
+    int32_t reserved0;
+    float tau;               /* config.tau */
+    float reserved1;
+    const float* state_min;  /* [state_dim] */
+    const float* state_max;  /* [state_dim] */
+    const float* action_min; /* [action_dim] (device OU clip) */
+    const float* action_max; /* [action_dim] (tanh scale, hydra_ddpg_network.py:92) */
+    const float* actor_lr;   /* [n_agents] per-agent (sweep settings differ in lr) */
+    const float* critic_lr;  /* [n_agents] */
+    const uint64_t* seed;    /* [n_agents] Philox keys of the device sampler / OU generator */
+    float ou_theta, ou_mu, ou_sigma; /* utils/config.py:19-21 (device OU generator) */
+    int32_t reserved2;
+} rlc_ddpg_config;
+
+const char* rlc_last_error(void);
+int rlc_version(void);
+int rlc_device_count(int* out_count);
+
+/* -- lifetime: DDPG_Network_Manager.__init__ (agents/DDPG.py:17-32) + ReplayBuffer.__init__
+ *    (utils/replaybuffer.py:16-23).  Networks start at zero; load them with rlc_ddpg_set_params. */
+int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out);
+int rlc_ddpg_destroy(rlc_ddpg* h);
+int rlc_ddpg_param_count(const rlc_ddpg* h, int64_t* out_p);
+int rlc_ddpg_sync(rlc_ddpg* h);                      /* hipStreamSynchronize on the handle's stream */
+
+/* -- parameters / optimizer state (parity taps; also checkpointing).
+ *    which: 0 online theta, 1 target theta', 2 actor-Adam m, 3 actor-Adam v, 4 critic-Adam m, 5 critic-Adam v */
+int rlc_ddpg_set_blob(rlc_ddpg* h, int32_t agent, int32_t which, const float* src, int64_t n);
+int rlc_ddpg_get_blob(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int64_t n);
+/* beta powers {actor b1^t, actor b2^t, critic b1^t, critic b2^t} (TF Adam accumulators, quirk Q2) */
+int rlc_ddpg_set_beta_powers(rlc_ddpg* h, int32_t agent, const float* pw4);
+int rlc_ddpg_get_beta_powers(rlc_ddpg* h, int32_t agent, float* pw4);
+/* theta' <- theta : HydraDDPGNetwork.init_target_network (hydra_ddpg_network.py:32,223-224) */
+int rlc_ddpg_init_target(rlc_ddpg* h, int32_t agent);
+
+/* -- replay: ReplayBuffer.add / get_size (utils/replaybuffer.py:25-30), FIFO eviction of the oldest
+ *    (utils/custom_collections.py:83-101).  Logical index 0 is the OLDEST stored transition. */
+int rlc_replay_add(rlc_ddpg* h, int32_t agent, const double* state, const double* action, double reward,
+                   const double* next_state, double transition_gamma);
+int rlc_replay_add_batch(rlc_ddpg* h, int32_t agent, int64_t n, const double* states, const double* actions,
+                         const double* rewards, const double* next_states, const double* gammas);
+/* every agent receives the same n transitions, already resident in HBM as fp32/fp64 SoA (bench path) */
+int rlc_replay_fill_all_dev(rlc_ddpg* h, int64_t n, const float* s_dev, const float* a_dev,
+                            const double* r_dev, const float* s2_dev, const double* g_dev);
+int rlc_replay_size(const rlc_ddpg* h, int32_t agent, int64_t* out_size);
+/* ReplayBuffer.sample_batch's gather (utils/replaybuffer.py:32-37 -> custom_collections.py:37-58) for
+ * caller-chosen logical indices: out arrays [k,S] [k,A] [k] [k,S] [k] float64 like the reference returns. */
+int rlc_replay_gather(rlc_ddpg* h, int32_t agent, const int64_t* logical_idx, int32_t k, double* states,
+                      double* actions, double* rewards, double* next_states, double* gammas);
+/* RandomAccessQueue.sample_n_k on the device (Philox; k distinct uniform logical indices in [0,size)) */
+int rlc_replay_sample_indices(rlc_ddpg* h, int32_t agent, int32_t k, int64_t* out_idx);
+
+/* -- acting: DDPG_Network_Manager.take_action's greedy part, predict_action on B=1
+ *    (agents/DDPG.py:36, hydra_ddpg_network.py:162-171).  states [n][S] for agents first..first+n-1,
+ *    out [n][A] = tanh(.)*action_max, fp32 like the Session.run fetch. */
+int rlc_ddpg_act(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions);
+/* same + device OU noise and clip (utils/exploration_policy.py:18-21); reset -> noise = mu (:23-24) */
+int rlc_ddpg_act_explore(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions);
+int rlc_ddpg_reset_noise(rlc_ddpg* h, int32_t first_agent, int32_t n);
+/* predict_qval (hydra_ddpg_network.py:183-193): q[n] for n (state, action) rows on ONE agent's online net */
+int rlc_ddpg_qval(rlc_ddpg* h, int32_t agent, int32_t n, const double* states, const double* actions, float* out_q);
+
+/* -- learning.
+ *  rlc_ddpg_update: BaseAgent.learn (agents/base_agent.py:65-70) for EVERY agent of the handle,
+ *    n_updates times: sample_batch + update_network (agents/DDPG.py:74-95) fused in one launch.
+ *    host_indices: NULL -> device Philox sampler; else int64 [n_agents][n_updates][batch] logical
+ *    indices (what the reference's RandomState produced) for exact-minibatch parity.
+ *    Fails if any agent holds fewer than batch_size transitions (utils/replaybuffer.py:34).
+ *  rlc_ddpg_update_batch: DDPG_Network_Manager.update_network(state, action, next_state, reward, gamma)
+ *    (agents/DDPG.py:74) on a caller-supplied minibatch for ONE agent. */
+int rlc_ddpg_update(rlc_ddpg* h, int32_t n_updates, const int64_t* host_indices);
+int rlc_ddpg_update_batch(rlc_ddpg* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+                          const double* next_states, const double* rewards, const double* gammas);
+/* kernel selection for A/B tests: 0 auto, 1 generic (any dims), 2 MFMA-tiled (gfx950 fp32 matrix cores) */
+int rlc_ddpg_set_kernel(rlc_ddpg* h, int32_t variant);
+int rlc_ddpg_get_kernel(const rlc_ddpg* h, int32_t* variant_in_use);
+
+/* -- debug taps of the LAST update of one agent (the 1e-5 checks): which: 0 q before the critic step
+ *    (train_critic's fetch, hydra_ddpg_network.py:155), 1 TD target y, 2 scaled actor output (DDPG.py:90),
+ *    3 dQ/da (DDPG.py:91).  n = batch (0,1) or batch*A (2,3). */
+int rlc_ddpg_last_tap(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int64_t n);
+/* which 4 / 5: the critic / actor optimizer's gradient blob (P floats, zeros where the gradient is None:
+ * hydra_ddpg_network.py:37,72) of the last update -- written only while enabled (extra HBM stores). */
+int rlc_ddpg_enable_grad_taps(rlc_ddpg* h, int32_t on);
+
+/* -- timing on the handle's stream (hipEvents): bench.py's roofline.achieved */
+int rlc_timer_begin(rlc_ddpg* h);
+int rlc_timer_end(rlc_ddpg* h, float* out_ms);   /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLCONTROL_HIP_H */

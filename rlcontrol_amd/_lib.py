@@ -1,0 +1,89 @@
+"""ctypes binding of librlcontrol_hip.so (include/rlcontrol_hip.h).
+
+The HIP library is the only compute path of this package: if it is missing, or no MI355X is
+visible, construction fails loudly -- there is no CPU fallback (the CPU restatement under oracle/
+is test infrastructure and is never imported from here).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librlcontrol_hip.so")
+
+# every symbol include/rlcontrol_hip.h declares (tests check the .so exports all of them)
+EXPORTS = (
+    "rlc_last_error", "rlc_version", "rlc_device_count",
+    "rlc_ddpg_create", "rlc_ddpg_destroy", "rlc_ddpg_param_count", "rlc_ddpg_sync",
+    "rlc_ddpg_set_blob", "rlc_ddpg_get_blob", "rlc_ddpg_set_beta_powers", "rlc_ddpg_get_beta_powers",
+    "rlc_ddpg_init_target",
+    "rlc_replay_add", "rlc_replay_add_batch", "rlc_replay_fill_all_dev", "rlc_replay_size",
+    "rlc_replay_gather", "rlc_replay_sample_indices",
+    "rlc_ddpg_act", "rlc_ddpg_act_explore", "rlc_ddpg_reset_noise", "rlc_ddpg_qval",
+    "rlc_ddpg_update", "rlc_ddpg_update_batch", "rlc_ddpg_set_kernel", "rlc_ddpg_get_kernel",
+    "rlc_ddpg_last_tap", "rlc_ddpg_enable_grad_taps",
+    "rlc_timer_begin", "rlc_timer_end",
+)
+
+
+class RlcError(RuntimeError):
+    pass
+
+
+class rlc_ddpg_config(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32), ("n_agents", ctypes.c_int32),
+        ("state_dim", ctypes.c_int32), ("action_dim", ctypes.c_int32),
+        ("shared_l1_dim", ctypes.c_int32), ("actor_l2_dim", ctypes.c_int32), ("critic_l2_dim", ctypes.c_int32),
+        ("batch_size", ctypes.c_int32), ("buffer_size", ctypes.c_int64),
+        ("clip_state", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("tau", ctypes.c_float), ("reserved1", ctypes.c_float),
+        ("state_min", ctypes.POINTER(ctypes.c_float)), ("state_max", ctypes.POINTER(ctypes.c_float)),
+        ("action_min", ctypes.POINTER(ctypes.c_float)), ("action_max", ctypes.POINTER(ctypes.c_float)),
+        ("actor_lr", ctypes.POINTER(ctypes.c_float)), ("critic_lr", ctypes.POINTER(ctypes.c_float)),
+        ("seed", ctypes.POINTER(ctypes.c_uint64)),
+        ("ou_theta", ctypes.c_float), ("ou_mu", ctypes.c_float), ("ou_sigma", ctypes.c_float),
+        ("reserved2", ctypes.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RlcError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); rlcontrol_amd has no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.rlc_last_error.restype = ctypes.c_char_p
+    for name in EXPORTS:
+        if name != "rlc_last_error":
+            getattr(lib, name).restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RlcError(load().rlc_last_error().decode("utf-8", "replace"))
+
+
+def fptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def iptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

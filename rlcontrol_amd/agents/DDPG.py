@@ -1,0 +1,75 @@
+"""DDPG agent on MI355X (mirrors agents/DDPG.py:16-103 + agents/network/hydra_ddpg_network.py).
+
+``DDPG(config)`` is constructed from the same ``Config`` the reference builds in main.py:160-163
+(env facts + json sweep values + CLI flags) and answers the same ``start/step/update/reset`` calls.
+The "hydra" network (shared first layer, actor head, critic head with the action concatenated
+last), its target copy, both TF-style Adam optimizers and the replay ring all live inside one
+``rlc_ddpg`` handle (include/rlcontrol_hip.h); this file only moves numpy arrays across the ABI.
+
+Manager-level API kept: ``take_action(state, is_train, is_start)``,
+``update_network(state, action, next_state, reward, gamma)``, ``reset()``, ``input_norm``.
+Added for the fused path: ``update_from_replay(logical_indices)`` and ``device_replay()``.
+"""
+import numpy as np
+
+from .base_agent import BaseAgent
+from .network.base_network_manager import BaseNetwork_Manager
+from ..hip_ddpg import DDPGPopulation, init_params
+
+
+class DDPG_Network_Manager(BaseNetwork_Manager):
+    def __init__(self, config):
+        super(DDPG_Network_Manager, self).__init__(config)
+        assert config.norm_type in ('none', 'input_norm'), \
+            "only norm_type 'input_norm'/'none' are accelerated (all shipped jsons use input_norm)"
+        self.population = DDPGPopulation(
+            n_agents=1, state_dim=config.state_dim, action_dim=config.action_dim,
+            shared_l1_dim=config.shared_l1_dim, actor_l2_dim=config.actor_l2_dim,
+            critic_l2_dim=config.critic_l2_dim, batch_size=config.batch_size,
+            buffer_size=int(config.buffer_size), tau=config.tau,
+            state_min=config.state_min, state_max=config.state_max,
+            action_min=config.action_min, action_max=config.action_max,
+            actor_lr=config.actor_lr, critic_lr=config.critic_lr,
+            seeds=[np.uint64(config.random_seed)],
+            clip_state=(config.norm_type != 'none'),
+            ou_theta=config.ou_theta, ou_mu=config.ou_mu, ou_sigma=config.ou_sigma,
+            device=int(getattr(config, "device", 0)))
+        kernel = getattr(config, "hip_kernel", "auto")
+        if kernel != "auto":
+            self.population.set_kernel(kernel)
+        # sess.run(global_variables_initializer()) + init_target_network() (agents/DDPG.py:28-32)
+        theta0 = init_params(config.state_dim, config.action_dim, config.shared_l1_dim, config.actor_l2_dim,
+                             config.critic_l2_dim, config.random_seed)
+        self.population.set_params(0, theta0, init_target=True)
+
+    def device_replay(self):
+        return (self.population, 0)
+
+    def take_action(self, state, is_train, is_start):
+        greedy_action = self.population.act(np.expand_dims(state, 0))[0]
+        if is_train:
+            if is_start:
+                self.train_ep_count += 1
+            self.train_global_steps += 1
+            if self.use_external_exploration:
+                chosen_action = self.exploration_policy.generate(greedy_action, self.train_global_steps)
+            else:
+                chosen_action = greedy_action
+        else:
+            if is_start:
+                self.eval_ep_count += 1
+            self.eval_global_steps += 1
+            chosen_action = greedy_action
+        return chosen_action
+
+    def update_network(self, state_batch, action_batch, next_state_batch, reward_batch, gamma_batch):
+        self.population.update_batch(0, state_batch, action_batch, next_state_batch, reward_batch, gamma_batch)
+
+    def update_from_replay(self, logical_indices):
+        self.population.update(1, host_indices=logical_indices)
+
+
+class DDPG(BaseAgent):
+    def __init__(self, config):
+        network_manager = DDPG_Network_Manager(config)
+        super(DDPG, self).__init__(config, network_manager)

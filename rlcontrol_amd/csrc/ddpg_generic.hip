@@ -1,0 +1,458 @@
+// ddpg_generic.hip -- dimension-generic fused DDPG update + acting kernels (fp32 VALU path).
+//
+// One workgroup per agent; n_updates sequential updates per launch.  Each update fuses what the
+// reference does in BaseAgent.learn (agents/base_agent.py:65-70): sample_batch
+// (utils/replaybuffer.py:32-37) and DDPG_Network_Manager.update_network (agents/DDPG.py:74-95,
+// seven Session.run calls) into one kernel iteration:
+//   gather -> target actor/critic on s' -> float64 TD target (Q5) -> critic forward/backward, MSE,
+//   TF-Adam (critic optimizer, incl. the shared trunk: Q1) -> actor forward with the UPDATED trunk ->
+//   dQ/da at the scaled action -> actor backward (batch SUM, unscaled tanh: Q3) -> TF-Adam (actor
+//   optimizer) -> Polyak on all ten tensors.
+// This is the any-shape path (arbitrary S, A, H1, HA, HC, B <= 128); the gfx950 matrix-core path for
+// the headline shapes is ddpg_mfma.hip.  Activations [B,H] live in a per-agent global scratch that
+// stays in the XCD's L2; per-sample vectors live in LDS.
+#include "rlc_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRows = 4;   // batch rows per thread-item in the dense loops
+
+struct Lds {
+    float *x, *x2, *a, *aout, *mu, *dqda, *dz, *q, *y, *dq;
+    double *r, *g;
+    long long* idx;
+    int* pool;
+    int* dups;
+};
+
+__host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* base, Lds* out) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = base ? base + off : nullptr;
+        off += (bytes + 15) & ~(size_t)15;
+        return p;
+    };
+    const int B = d.B, S = d.S, A = d.A;
+    double* r = (double*)take(sizeof(double) * B);
+    double* g = (double*)take(sizeof(double) * B);
+    long long* idx = (long long*)take(sizeof(long long) * RLC_MAX_BATCH);
+    float* x = (float*)take(sizeof(float) * B * S);
+    float* x2 = (float*)take(sizeof(float) * B * S);
+    float* a = (float*)take(sizeof(float) * B * A);
+    float* aout = (float*)take(sizeof(float) * B * A);
+    float* mu = (float*)take(sizeof(float) * B * A);
+    float* dqda = (float*)take(sizeof(float) * B * A);
+    float* dz = (float*)take(sizeof(float) * B * A);
+    float* q = (float*)take(sizeof(float) * B);
+    float* y = (float*)take(sizeof(float) * B);
+    float* dq = (float*)take(sizeof(float) * B);
+    int* pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
+    int* dups = (int*)take(sizeof(int) * 4);
+    if (out) {
+        out->r = r; out->g = g; out->idx = idx; out->x = x; out->x2 = x2; out->a = a; out->aout = aout;
+        out->mu = mu; out->dqda = dqda; out->dz = dz; out->q = q; out->y = y; out->dq = dq;
+        out->pool = pool; out->dups = dups;
+    }
+    return off;
+}
+
+// Y[b,n] = act( sum_k X[b,k] W[k,n] + sum_j E[b,j] W[K+j,n] + bias[n] );  act: 0 none, 1 relu, 2 tanh
+// X: [B,K] row-major (ldx); E: optional extra input columns (the action, concatenated LAST:
+// hydra_ddpg_network.py:128).  Lanes run over n (coalesced W rows); X/E reads are wave-uniform.
+__device__ void blk_dense(const float* X, int ldx, int K, const float* E, int Ke, const float* W,
+                          const float* bias, int N, float* Y, int ldy, int B, int act) {
+    const int rb = (B + kRows - 1) / kRows;
+    for (int it = threadIdx.x; it < rb * N; it += kThreads) {
+        const int n = it % N;
+        const int b0 = (it / N) * kRows;
+        float acc[kRows];
+#pragma unroll
+        for (int i = 0; i < kRows; i++) acc[i] = 0.0f;
+        for (int k = 0; k < K; k++) {
+            const float w = W[(size_t)k * N + n];
+#pragma unroll
+            for (int i = 0; i < kRows; i++) {
+                const int b = min(b0 + i, B - 1);
+                acc[i] += X[(size_t)b * ldx + k] * w;
+            }
+        }
+        for (int j = 0; j < Ke; j++) {
+            const float w = W[(size_t)(K + j) * N + n];
+#pragma unroll
+            for (int i = 0; i < kRows; i++) {
+                const int b = min(b0 + i, B - 1);
+                acc[i] += E[b * Ke + j] * w;
+            }
+        }
+        const float bs = bias[n];
+#pragma unroll
+        for (int i = 0; i < kRows; i++) {
+            if (b0 + i < B) {
+                float v = acc[i] + bs;
+                if (act == 1) v = fmaxf(v, 0.0f);
+                else if (act == 2) v = tanhf(v);
+                Y[(size_t)(b0 + i) * ldy + n] = v;
+            }
+        }
+    }
+}
+
+// dX[b,k] = (Hk[b,k] > 0) ? sum_n dY[b,n] W[k,n] : 0      (W[k][n] rows k < K only)
+__device__ void blk_dense_bwd_input(const float* dY, int N, const float* W, const float* Hk, int K, float* dX,
+                                    int B) {
+    const int rb = (B + kRows - 1) / kRows;
+    for (int it = threadIdx.x; it < rb * K; it += kThreads) {
+        const int k = it % K;
+        const int b0 = (it / K) * kRows;
+        float acc[kRows];
+#pragma unroll
+        for (int i = 0; i < kRows; i++) acc[i] = 0.0f;
+        for (int n = 0; n < N; n++) {
+            const float w = W[(size_t)k * N + n];
+#pragma unroll
+            for (int i = 0; i < kRows; i++) {
+                const int b = min(b0 + i, B - 1);
+                acc[i] += dY[(size_t)b * N + n] * w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRows; i++)
+            if (b0 + i < B) dX[(size_t)(b0 + i) * K + k] = Hk[(size_t)(b0 + i) * K + k] > 0.0f ? acc[i] : 0.0f;
+    }
+}
+
+struct AdamCtx {
+    float* theta; float* m; float* v; float alpha; float* tap;   // tap may be null
+};
+
+__device__ __forceinline__ void adam_apply(const AdamCtx& c, int p, float g) {
+    float m = c.m[p], v = c.v[p];
+    const float nv = adam_step(c.theta[p], g, m, v, c.alpha);
+    c.m[p] = m; c.v[p] = v; c.theta[p] = nv;
+    if (c.tap) c.tap[p] = g;
+}
+
+// gradient of a dense layer's weights/bias + Adam, one parameter element per thread-item:
+//   W[k,n] (k < K): sum_b X[b,k] dY[b,n];  W[K+j,n]: sum_b E[b,j] dY[b,n];  bias[n]: sum_b dY[b,n]
+__device__ void blk_dense_grad_adam(const float* X, int ldx, int K, const float* E, int Ke, const float* dY,
+                                    int N, int B, const AdamCtx& c, int oW, int ob) {
+    const int rows = K + Ke + 1;   // last "row" is the bias
+    for (int it = threadIdx.x; it < rows * N; it += kThreads) {
+        const int n = it % N;
+        const int k = it / N;
+        float g = 0.0f;
+        if (k < K) {
+            for (int b = 0; b < B; b++) g += X[(size_t)b * ldx + k] * dY[(size_t)b * N + n];
+            adam_apply(c, oW + k * N + n, g);
+        } else if (k < K + Ke) {
+            for (int b = 0; b < B; b++) g += E[b * Ke + (k - K)] * dY[(size_t)b * N + n];
+            adam_apply(c, oW + k * N + n, g);
+        } else {
+            for (int b = 0; b < B; b++) g += dY[(size_t)b * N + n];
+            adam_apply(c, ob + n, g);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDev dv, int first_agent,
+                                                                           int n_updates, int source,
+                                                                           const long long* host_idx,
+                                                                           int grad_taps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const RlcDims d = dv.d;
+    const int S = d.S, A = d.A, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
+    const int agent = first_agent + blockIdx.x;
+    const int tid = threadIdx.x;
+    Lds L;
+    lds_carve(d, smem, &L);
+
+    float* th = dv.theta + (size_t)agent * d.Ppad;
+    float* tt = dv.theta_t + (size_t)agent * d.Ppad;
+    float* sc = dv.scratch + (size_t)agent * dv.scratch_stride;
+    float* h1 = sc;
+    float* h2 = h1 + (size_t)B * H1;
+    float* g2 = h2 + (size_t)B * HA;
+    float* d2 = g2 + (size_t)B * HC;
+    float* dh1 = d2 + (size_t)B * max(HA, HC);
+    float* pw = dv.pw + agent * 4;
+    const float lr_a = dv.actor_lr[agent], lr_c = dv.critic_lr[agent];
+    float* tap_gc = grad_taps ? dv.tap_gc + (size_t)agent * d.Ppad : nullptr;
+    float* tap_ga = grad_taps ? dv.tap_ga + (size_t)agent * d.Ppad : nullptr;
+
+    for (int u = 0; u < n_updates; u++) {
+        // ---- sample + gather (utils/replaybuffer.py:32-37) ----
+        const RlcRingMeta ring = dv.ring[agent];
+        if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
+            const unsigned long long call = dv.sample_ctr[agent];
+            __syncthreads();
+            rlc_sample_distinct(ring.size, B, dv.seed[agent], call, L.pool, L.idx, L.dups);
+            if (tid == 0) dv.sample_ctr[agent] = call + 1;
+        } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
+            for (int b = tid; b < B; b += kThreads)
+                L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + u) * B + b];
+        }
+        __syncthreads();
+        for (int b = tid; b < B; b += kThreads) {
+            const float *ps, *pa, *ps2;
+            if (source == RLC_SRC_STAGING) {
+                const size_t slot = (size_t)agent * RLC_MAX_BATCH + b;
+                ps = dv.gs + slot * S; pa = dv.ga + slot * A; ps2 = dv.gs2 + slot * S;
+                L.r[b] = dv.gr[slot]; L.g[b] = dv.gg[slot];
+            } else {
+                const size_t slot = (size_t)agent * dv.cap + ring_slot(ring, dv.cap, L.idx[b]);
+                ps = dv.rs + slot * S; pa = dv.ra + slot * A; ps2 = dv.rs2 + slot * S;
+                L.r[b] = dv.rr[slot]; L.g[b] = dv.rg[slot];
+            }
+            for (int i = 0; i < S; i++) {
+                L.x[b * S + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x2[b * S + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+            }
+            for (int j = 0; j < A; j++) L.a[b * A + j] = pa[j];
+        }
+        __syncthreads();
+
+        // ---- steps 1-2: target actor / critic on s' (DDPG.py:77) ----
+        blk_dense(L.x2, S, S, nullptr, 0, tt + d.oW1, tt + d.ob1, H1, h1, H1, B, 1);
+        __syncthreads();
+        blk_dense(h1, H1, H1, nullptr, 0, tt + d.oWa2, tt + d.oba2, HA, h2, HA, B, 1);
+        __syncthreads();
+        blk_dense(h2, HA, HA, nullptr, 0, tt + d.oWa3, tt + d.oba3, A, L.mu, A, B, 2);
+        __syncthreads();
+        for (int i = tid; i < B * A; i += kThreads) L.aout[i] = L.mu[i] * dv.amax[i % A];
+        __syncthreads();
+        blk_dense(h1, H1, H1, L.aout, A, tt + d.oWc2, tt + d.obc2, HC, g2, HC, B, 1);
+        __syncthreads();
+        blk_dense(g2, HC, HC, nullptr, 0, tt + d.oWc3, tt + d.obc3, 1, L.q, 1, B, 0);
+        __syncthreads();
+        // TD target in float64, then the fp32 placeholder cast (DDPG.py:80-84)
+        for (int b = tid; b < B; b += kThreads) {
+            const float y = (float)(L.r[b] + L.g[b] * (double)L.q[b]);
+            L.y[b] = y;
+            dv.tap_y[(size_t)agent * RLC_MAX_BATCH + b] = y;
+        }
+        __syncthreads();
+
+        // ---- step 3: critic step (hydra_ddpg_network.py:71-72) ----
+        blk_dense(L.x, S, S, nullptr, 0, th + d.oW1, th + d.ob1, H1, h1, H1, B, 1);
+        __syncthreads();
+        blk_dense(h1, H1, H1, L.a, A, th + d.oWc2, th + d.obc2, HC, g2, HC, B, 1);
+        __syncthreads();
+        blk_dense(g2, HC, HC, nullptr, 0, th + d.oWc3, th + d.obc3, 1, L.q, 1, B, 0);
+        __syncthreads();
+        for (int b = tid; b < B; b += kThreads) {
+            dv.tap_q[(size_t)agent * RLC_MAX_BATCH + b] = L.q[b];
+            L.dq[b] = 2.0f * (L.q[b] - L.y[b]) / (float)B;          // d mean((y-q)^2) / dq
+        }
+        __syncthreads();
+        for (int it = tid; it < B * HC; it += kThreads) {
+            const int b = it / HC, n = it % HC;
+            d2[it] = g2[it] > 0.0f ? L.dq[b] * th[d.oWc3 + n] : 0.0f;
+        }
+        __syncthreads();
+        blk_dense_bwd_input(d2, HC, th + d.oWc2, h1, H1, dh1, B);    // uses the pre-step Wc2
+        __syncthreads();
+        {
+            const AdamCtx c = {th, dv.m_c + (size_t)agent * d.Ppad, dv.v_c + (size_t)agent * d.Ppad,
+                               adam_alpha(lr_c, pw[2], pw[3]), tap_gc};
+            blk_dense_grad_adam(g2, HC, HC, nullptr, 0, L.dq, 1, B, c, d.oWc3, d.obc3);
+            blk_dense_grad_adam(h1, H1, H1, L.a, A, d2, HC, B, c, d.oWc2, d.obc2);
+            blk_dense_grad_adam(L.x, S, S, nullptr, 0, dh1, H1, B, c, d.oW1, d.ob1);
+        }
+        __syncthreads();
+        if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
+
+        // ---- step 4: actor forward with the updated trunk (DDPG.py:90) ----
+        blk_dense(L.x, S, S, nullptr, 0, th + d.oW1, th + d.ob1, H1, h1, H1, B, 1);
+        __syncthreads();
+        blk_dense(h1, H1, H1, nullptr, 0, th + d.oWa2, th + d.oba2, HA, h2, HA, B, 1);
+        __syncthreads();
+        blk_dense(h2, HA, HA, nullptr, 0, th + d.oWa3, th + d.oba3, A, L.mu, A, B, 2);
+        __syncthreads();
+        for (int i = tid; i < B * A; i += kThreads) {
+            const float ao = L.mu[i] * dv.amax[i % A];
+            L.aout[i] = ao;
+            dv.tap_aout[(size_t)agent * RLC_MAX_BATCH * A + i] = ao;
+        }
+        __syncthreads();
+        // ---- step 5: dQ/da at the scaled action with the updated critic (DDPG.py:91) ----
+        blk_dense(h1, H1, H1, L.aout, A, th + d.oWc2, th + d.obc2, HC, g2, HC, B, 1);
+        __syncthreads();
+        for (int it = tid; it < B * A; it += kThreads) {
+            const int b = it / A, j = it % A;
+            float acc = 0.0f;
+            for (int n = 0; n < HC; n++)
+                if (g2[(size_t)b * HC + n] > 0.0f) acc += th[d.oWc3 + n] * th[d.oWc2 + (size_t)(H1 + j) * HC + n];
+            L.dqda[it] = acc;
+            dv.tap_dqda[(size_t)agent * RLC_MAX_BATCH * A + it] = acc;
+            L.dz[it] = -acc * (1.0f - L.mu[it] * L.mu[it]);          // grad_ys = -dQ/da on tanh output (Q3)
+        }
+        __syncthreads();
+        // ---- step 6: actor step ----
+        for (int it = tid; it < B * HA; it += kThreads) {
+            const int b = it / HA, n = it % HA;
+            float acc = 0.0f;
+            for (int j = 0; j < A; j++) acc += L.dz[b * A + j] * th[d.oWa3 + n * A + j];
+            d2[it] = h2[it] > 0.0f ? acc : 0.0f;
+        }
+        __syncthreads();
+        blk_dense_bwd_input(d2, HA, th + d.oWa2, h1, H1, dh1, B);
+        __syncthreads();
+        {
+            const AdamCtx c = {th, dv.m_a + (size_t)agent * d.Ppad, dv.v_a + (size_t)agent * d.Ppad,
+                               adam_alpha(lr_a, pw[0], pw[1]), tap_ga};
+            blk_dense_grad_adam(h2, HA, HA, nullptr, 0, L.dz, A, B, c, d.oWa3, d.oba3);
+            blk_dense_grad_adam(h1, H1, H1, nullptr, 0, d2, HA, B, c, d.oWa2, d.oba2);
+            blk_dense_grad_adam(L.x, S, S, nullptr, 0, dh1, H1, B, c, d.oW1, d.ob1);
+        }
+        __syncthreads();
+        if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
+        // ---- step 7: Polyak on all ten tensors (hydra_ddpg_network.py:29) ----
+        for (int p = tid; p < d.P; p += kThreads) {
+            const float t = tt[p];
+            tt[p] = t + dv.tau * (th[p] - t);
+        }
+        __syncthreads();
+    }
+}
+
+// greedy action (+ optional device OU noise) for one state per agent: predict_action on B=1
+// (agents/DDPG.py:36-44; utils/exploration_policy.py:18-21).  One workgroup per agent.
+__global__ __launch_bounds__(kThreads) void rlc_ddpg_act_kernel(RlcDev dv, int first_agent, const float* states,
+                                                                float* out, int explore) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const RlcDims d = dv.d;
+    const int S = d.S, A = d.A, H1 = d.H1, HA = d.HA;
+    const int agent = first_agent + blockIdx.x;
+    const int tid = threadIdx.x;
+    float* x = (float*)smem;
+    float* h1 = x + ((S + 3) & ~3);
+    float* h2 = h1 + ((H1 + 3) & ~3);
+    const float* th = dv.theta + (size_t)agent * d.Ppad;
+    for (int i = tid; i < S; i += kThreads)
+        x[i] = clip_state_val(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin[i], dv.smax[i]);
+    __syncthreads();
+    for (int k = tid; k < H1; k += kThreads) {
+        float acc = 0.0f;
+        for (int i = 0; i < S; i++) acc += x[i] * th[d.oW1 + i * H1 + k];
+        h1[k] = fmaxf(acc + th[d.ob1 + k], 0.0f);
+    }
+    __syncthreads();
+    for (int n = tid; n < HA; n += kThreads) {
+        float acc = 0.0f;
+        for (int k = 0; k < H1; k++) acc += h1[k] * th[d.oWa2 + (size_t)k * HA + n];
+        h2[n] = fmaxf(acc + th[d.oba2 + n], 0.0f);
+    }
+    __syncthreads();
+    // one wave per output action: 64-lane shuffle reduction over HA
+    const int wave = tid / RLC_WAVE, lane = tid % RLC_WAVE;
+    for (int j = wave; j < A; j += kThreads / RLC_WAVE) {
+        float acc = 0.0f;
+        for (int n = lane; n < HA; n += RLC_WAVE) acc += h2[n] * th[d.oWa3 + n * A + j];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, RLC_WAVE);
+        if (lane == 0) {
+            float act = tanhf(acc + th[d.oba3 + j]) * dv.amax[j];
+            if (explore) {
+                // OU: n <- n + N(mu, sigma) - theta*n ; clip(a + n)
+                const unsigned long long ctr = dv.noise_ctr[agent];
+                const Philox4 p = philox4x32_10(dv.seed[agent] ^ 0x5DEECE66Dull, ctr, (unsigned long long)(j / 2));
+                float n0, n1;
+                philox_normal2(p, n0, n1);
+                const float z = (j & 1) ? n1 : n0;
+                float noise = dv.ou_state[agent * A + j];
+                noise += (dv.ou_mu + dv.ou_sigma * z) - noise * dv.ou_theta;
+                dv.ou_state[agent * A + j] = noise;
+                act = fminf(fmaxf(act + noise, dv.amin[j]), dv.amax[j]);
+            }
+            out[(size_t)blockIdx.x * A + j] = act;
+        }
+    }
+    __syncthreads();
+    if (explore && tid == 0) dv.noise_ctr[agent] += 1;
+}
+
+__global__ void rlc_reset_noise_kernel(RlcDev dv, int first_agent, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * dv.d.A) dv.ou_state[(size_t)first_agent * dv.d.A + i] = dv.ou_mu;
+}
+
+// Q(s,a) rows on one agent's online network: predict_qval (hydra_ddpg_network.py:183-193).
+// One workgroup per row.
+__global__ __launch_bounds__(kThreads) void rlc_ddpg_qval_kernel(RlcDev dv, int agent, const float* states,
+                                                                 const float* actions, float* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const RlcDims d = dv.d;
+    const int S = d.S, A = d.A, H1 = d.H1, HC = d.HC;
+    const int tid = threadIdx.x, row = blockIdx.x;
+    float* x = (float*)smem;
+    float* h1 = x + ((S + A + 3) & ~3);
+    float* red = h1 + ((H1 + 3) & ~3);
+    const float* th = dv.theta + (size_t)agent * d.Ppad;
+    for (int i = tid; i < S; i += kThreads)
+        x[i] = clip_state_val(states[(size_t)row * S + i], dv.clip_state, dv.smin[i], dv.smax[i]);
+    for (int j = tid; j < A; j += kThreads) x[S + j] = actions[(size_t)row * A + j];
+    __syncthreads();
+    for (int k = tid; k < H1; k += kThreads) {
+        float acc = 0.0f;
+        for (int i = 0; i < S; i++) acc += x[i] * th[d.oW1 + i * H1 + k];
+        h1[k] = fmaxf(acc + th[d.ob1 + k], 0.0f);
+    }
+    __syncthreads();
+    float part = 0.0f;
+    for (int n = tid; n < HC; n += kThreads) {
+        float acc = 0.0f;
+        for (int k = 0; k < H1; k++) acc += h1[k] * th[d.oWc2 + (size_t)k * HC + n];
+        for (int j = 0; j < A; j++) acc += x[S + j] * th[d.oWc2 + (size_t)(H1 + j) * HC + n];
+        part += fmaxf(acc + th[d.obc2 + n], 0.0f) * th[d.oWc3 + n];
+    }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, RLC_WAVE);
+    if (tid % RLC_WAVE == 0) red[tid / RLC_WAVE] = part;
+    __syncthreads();
+    if (tid == 0) {
+        float q = 0.0f;
+        for (int w = 0; w < kThreads / RLC_WAVE; w++) q += red[w];
+        out[row] = q + th[d.obc3];
+    }
+}
+
+}  // namespace
+
+size_t rlc_generic_scratch_floats(const RlcDims& d) {
+    const size_t B = d.B;
+    return B * d.H1 * 2 + B * d.HA + B * d.HC + B * (size_t)(d.HA > d.HC ? d.HA : d.HC);
+}
+
+int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                                   const long long* idx_dev, int grad_taps, hipStream_t st) {
+    const size_t lds = lds_carve(dv.d, nullptr, nullptr);
+    RLC_REQUIRE(lds <= 160 * 1024, "generic DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
+    hipLaunchKernelGGL(rlc_ddpg_update_generic_kernel, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent,
+                       n_updates, source, idx_dev, grad_taps);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
+int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states_dev, float* out_dev, int explore,
+                   hipStream_t st) {
+    const size_t lds = sizeof(float) * (((dv.d.S + 3) & ~3) + ((dv.d.H1 + 3) & ~3) + ((dv.d.HA + 3) & ~3));
+    hipLaunchKernelGGL(rlc_ddpg_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, out_dev,
+                       explore);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
+int rlc_launch_reset_noise(const RlcDev& dv, int first_agent, int n, hipStream_t st) {
+    const int total = n * dv.d.A;
+    hipLaunchKernelGGL(rlc_reset_noise_kernel, dim3((total + 255) / 256), dim3(256), 0, st, dv, first_agent, n);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
+int rlc_launch_qval(const RlcDev& dv, int agent, int n, const float* states_dev, const float* actions_dev,
+                    float* out_dev, hipStream_t st) {
+    const size_t lds = sizeof(float) * (((dv.d.S + dv.d.A + 3) & ~3) + ((dv.d.H1 + 3) & ~3) + 8);
+    hipLaunchKernelGGL(rlc_ddpg_qval_kernel, dim3(n), dim3(kThreads), lds, st, dv, agent, states_dev, actions_dev,
+                       out_dev);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}

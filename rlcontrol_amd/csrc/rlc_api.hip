@@ -1,0 +1,618 @@
+// rlc_api.hip -- the C ABI of librlcontrol_hip.so (declared in include/rlcontrol_hip.h).
+// Host-side handle management; all compute is in the kernel translation units.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "rlc_common.h"
+
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+
+void rlc_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct rlc_ddpg {
+    RlcDev dv;
+    int device;
+    hipStream_t st;
+    hipEvent_t ev0, ev1;
+    std::vector<RlcRingMeta> ring;       // host mirror of the ring metadata
+    std::vector<void*> allocs;           // every hipMalloc of this handle
+    long long* idx_dev; size_t idx_cap;  // host-index upload buffer
+    float* io_dev; size_t io_cap;        // act / qval / gather staging (device, bytes)
+    void* io_host; size_t io_host_cap;   // pinned host staging (bytes)
+    int variant;                         // requested: 0 auto, 1 generic, 2 mfma
+    int grad_taps;
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(rlc_ddpg* h, T** out, size_t count, bool zero = true) {
+    void* p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    RLC_HIP(hipMalloc(&p, bytes));
+    if (zero) RLC_HIP(hipMemsetAsync(p, 0, bytes, h->st));
+    h->allocs.push_back(p);
+    *out = (T*)p;
+    return 0;
+}
+
+int ensure_io(rlc_ddpg* h, size_t bytes) {
+    if (bytes > h->io_cap) {
+        RLC_HIP(hipStreamSynchronize(h->st));
+        if (h->io_dev) RLC_HIP(hipFree(h->io_dev));
+        h->io_dev = nullptr;
+        h->io_cap = 0;
+        const size_t cap = bytes * 2;
+        RLC_HIP(hipMalloc((void**)&h->io_dev, cap));
+        h->io_cap = cap;
+    }
+    if (bytes > h->io_host_cap) {
+        RLC_HIP(hipStreamSynchronize(h->st));
+        if (h->io_host) RLC_HIP(hipHostFree(h->io_host));
+        h->io_host = nullptr;
+        h->io_host_cap = 0;
+        const size_t cap = bytes * 2;
+        RLC_HIP(hipHostMalloc(&h->io_host, cap, hipHostMallocDefault));
+        h->io_host_cap = cap;
+    }
+    return 0;
+}
+
+int check_agent(const rlc_ddpg* h, int agent) {
+    RLC_REQUIRE(h != nullptr, "null handle");
+    RLC_REQUIRE(agent >= 0 && agent < h->dv.n_agents, "agent %d out of range [0,%d)", agent, h->dv.n_agents);
+    return 0;
+}
+
+float* blob_ptr(rlc_ddpg* h, int which) {
+    switch (which) {
+        case 0: return h->dv.theta;
+        case 1: return h->dv.theta_t;
+        case 2: return h->dv.m_a;
+        case 3: return h->dv.v_a;
+        case 4: return h->dv.m_c;
+        case 5: return h->dv.v_c;
+        default: return nullptr;
+    }
+}
+
+int use_device(const rlc_ddpg* h) {
+    RLC_HIP(hipSetDevice(h->device));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rlc_last_error(void) { return g_err; }
+
+int rlc_version(void) { return 100; }
+
+int rlc_device_count(int* out_count) {
+    RLC_REQUIRE(out_count != nullptr, "null out_count");
+    int n = 0;
+    RLC_HIP(hipGetDeviceCount(&n));
+    *out_count = n;
+    return 0;
+}
+
+int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out) {
+    RLC_REQUIRE(cfg && out, "null argument");
+    RLC_REQUIRE(cfg->n_agents >= 1, "n_agents must be >= 1 (got %d)", cfg->n_agents);
+    RLC_REQUIRE(cfg->state_dim >= 1 && cfg->action_dim >= 1, "state_dim/action_dim must be >= 1");
+    RLC_REQUIRE(cfg->shared_l1_dim >= 1 && cfg->actor_l2_dim >= 1 && cfg->critic_l2_dim >= 1,
+                "layer widths must be >= 1");
+    RLC_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= RLC_MAX_BATCH, "batch_size %d outside [1,%d]",
+                cfg->batch_size, RLC_MAX_BATCH);
+    RLC_REQUIRE(cfg->buffer_size >= 1, "buffer_size must be >= 1");
+    RLC_REQUIRE(cfg->state_min && cfg->state_max && cfg->action_min && cfg->action_max, "null bounds array");
+    RLC_REQUIRE(cfg->actor_lr && cfg->critic_lr && cfg->seed, "null per-agent array");
+    int ndev = 0;
+    RLC_HIP(hipGetDeviceCount(&ndev));
+    RLC_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "device %d not present (%d visible)", cfg->device, ndev);
+    RLC_HIP(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    RLC_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    RLC_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
+                "librlcontrol_hip is built for gfx950 (MI355X) only; device %d is %s", cfg->device,
+                prop.gcnArchName);
+
+    rlc_ddpg* h = new rlc_ddpg();
+    memset(&h->dv, 0, sizeof(h->dv));
+    h->device = cfg->device;
+    h->idx_dev = nullptr; h->idx_cap = 0;
+    h->io_dev = nullptr; h->io_cap = 0;
+    h->io_host = nullptr; h->io_host_cap = 0;
+    h->variant = 0;
+    h->grad_taps = 0;
+    if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
+        rlc_set_error("hipStreamCreate failed");
+        delete h;
+        return 1;
+    }
+    (void)hipEventCreate(&h->ev0);
+    (void)hipEventCreate(&h->ev1);
+
+    RlcDev& dv = h->dv;
+    dv.d = rlc_make_dims(cfg->state_dim, cfg->action_dim, cfg->shared_l1_dim, cfg->actor_l2_dim,
+                         cfg->critic_l2_dim, cfg->batch_size);
+    dv.n_agents = cfg->n_agents;
+    dv.cap = cfg->buffer_size;
+    dv.clip_state = cfg->clip_state;
+    dv.tau = cfg->tau;
+    dv.ou_theta = cfg->ou_theta; dv.ou_mu = cfg->ou_mu; dv.ou_sigma = cfg->ou_sigma;
+    const size_t NA = cfg->n_agents, PP = dv.d.Ppad, S = dv.d.S, A = dv.d.A;
+    const size_t cap = (size_t)dv.cap;
+
+    int rc = 0;
+#define TRY(x) do { rc = (x); if (rc) { rlc_ddpg_destroy(h); return rc; } } while (0)
+    TRY(dmalloc(h, &dv.theta, NA * PP));
+    TRY(dmalloc(h, &dv.theta_t, NA * PP));
+    TRY(dmalloc(h, &dv.m_a, NA * PP));
+    TRY(dmalloc(h, &dv.v_a, NA * PP));
+    TRY(dmalloc(h, &dv.m_c, NA * PP));
+    TRY(dmalloc(h, &dv.v_c, NA * PP));
+    TRY(dmalloc(h, &dv.pw, NA * 4));
+    float *lr_a, *lr_c, *smin, *smax, *amin, *amax;
+    unsigned long long* seed;
+    TRY(dmalloc(h, &lr_a, NA)); TRY(dmalloc(h, &lr_c, NA)); TRY(dmalloc(h, &seed, NA));
+    TRY(dmalloc(h, &smin, S)); TRY(dmalloc(h, &smax, S)); TRY(dmalloc(h, &amin, A)); TRY(dmalloc(h, &amax, A));
+    dv.actor_lr = lr_a; dv.critic_lr = lr_c; dv.seed = seed;
+    dv.smin = smin; dv.smax = smax; dv.amin = amin; dv.amax = amax;
+    // replay SoA (not zeroed: 288 GB parts make this the big allocation; slots are written before read)
+    TRY(dmalloc(h, &dv.rs, NA * cap * S, false));
+    TRY(dmalloc(h, &dv.rs2, NA * cap * S, false));
+    TRY(dmalloc(h, &dv.ra, NA * cap * A, false));
+    TRY(dmalloc(h, &dv.rr, NA * cap, false));
+    TRY(dmalloc(h, &dv.rg, NA * cap, false));
+    TRY(dmalloc(h, &dv.ring, NA));
+    TRY(dmalloc(h, &dv.gs, NA * RLC_MAX_BATCH * S));
+    TRY(dmalloc(h, &dv.gs2, NA * RLC_MAX_BATCH * S));
+    TRY(dmalloc(h, &dv.ga, NA * RLC_MAX_BATCH * A));
+    TRY(dmalloc(h, &dv.gr, NA * RLC_MAX_BATCH));
+    TRY(dmalloc(h, &dv.gg, NA * RLC_MAX_BATCH));
+    TRY(dmalloc(h, &dv.sample_ctr, NA));
+    TRY(dmalloc(h, &dv.noise_ctr, NA));
+    TRY(dmalloc(h, &dv.ou_state, NA * A));
+    TRY(dmalloc(h, &dv.tap_q, NA * RLC_MAX_BATCH));
+    TRY(dmalloc(h, &dv.tap_y, NA * RLC_MAX_BATCH));
+    TRY(dmalloc(h, &dv.tap_aout, NA * RLC_MAX_BATCH * A));
+    TRY(dmalloc(h, &dv.tap_dqda, NA * RLC_MAX_BATCH * A));
+    dv.tap_gc = nullptr; dv.tap_ga = nullptr;
+    dv.scratch_stride = (long long)((rlc_generic_scratch_floats(dv.d) + 63) & ~(size_t)63);
+    TRY(dmalloc(h, &dv.scratch, NA * (size_t)dv.scratch_stride, false));
+#undef TRY
+
+    // constants
+    std::vector<float> pw(NA * 4);
+    for (size_t i = 0; i < NA; i++) { pw[4 * i] = 0.9f; pw[4 * i + 1] = 0.999f; pw[4 * i + 2] = 0.9f; pw[4 * i + 3] = 0.999f; }
+    std::vector<float> ou(NA * A, cfg->ou_mu);
+    hipError_t e = hipSuccess;
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->st);
+    };
+    up(dv.pw, pw.data(), NA * 4 * sizeof(float));
+    up(dv.ou_state, ou.data(), NA * A * sizeof(float));
+    up(lr_a, cfg->actor_lr, NA * sizeof(float));
+    up(lr_c, cfg->critic_lr, NA * sizeof(float));
+    up(seed, cfg->seed, NA * sizeof(unsigned long long));
+    up(smin, cfg->state_min, S * sizeof(float));
+    up(smax, cfg->state_max, S * sizeof(float));
+    up(amin, cfg->action_min, A * sizeof(float));
+    up(amax, cfg->action_max, A * sizeof(float));
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    if (e != hipSuccess) {
+        rlc_set_error("rlc_ddpg_create: upload failed: %s", hipGetErrorString(e));
+        rlc_ddpg_destroy(h);
+        return 1;
+    }
+    h->ring.assign(NA, RlcRingMeta{0, 0});
+    *out = h;
+    return 0;
+}
+
+int rlc_ddpg_destroy(rlc_ddpg* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->st);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->idx_dev) (void)hipFree(h->idx_dev);
+    if (h->io_dev) (void)hipFree(h->io_dev);
+    if (h->io_host) (void)hipHostFree(h->io_host);
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->st);
+    delete h;
+    return 0;
+}
+
+int rlc_ddpg_param_count(const rlc_ddpg* h, int64_t* out_p) {
+    RLC_REQUIRE(h && out_p, "null argument");
+    *out_p = h->dv.d.P;
+    return 0;
+}
+
+int rlc_ddpg_sync(rlc_ddpg* h) {
+    RLC_REQUIRE(h, "null handle");
+    if (use_device(h)) return 1;
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_ddpg_set_blob(rlc_ddpg* h, int32_t agent, int32_t which, const float* src, int64_t n) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    float* base = blob_ptr(h, which);
+    RLC_REQUIRE(base && src, "bad blob selector %d or null src", which);
+    RLC_REQUIRE(n == h->dv.d.P, "blob length %lld != parameter count %d", (long long)n, h->dv.d.P);
+    RLC_HIP(hipMemcpyAsync(base + (size_t)agent * h->dv.d.Ppad, src, n * sizeof(float), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_ddpg_get_blob(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    float* base = blob_ptr(h, which);
+    RLC_REQUIRE(base && dst, "bad blob selector %d or null dst", which);
+    RLC_REQUIRE(n == h->dv.d.P, "blob length %lld != parameter count %d", (long long)n, h->dv.d.P);
+    RLC_HIP(hipMemcpyAsync(dst, base + (size_t)agent * h->dv.d.Ppad, n * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_ddpg_set_beta_powers(rlc_ddpg* h, int32_t agent, const float* pw4) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(pw4, "null pw4");
+    RLC_HIP(hipMemcpyAsync(h->dv.pw + agent * 4, pw4, 4 * sizeof(float), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_ddpg_get_beta_powers(rlc_ddpg* h, int32_t agent, float* pw4) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(pw4, "null pw4");
+    RLC_HIP(hipMemcpyAsync(pw4, h->dv.pw + agent * 4, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_ddpg_init_target(rlc_ddpg* h, int32_t agent) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    const size_t off = (size_t)agent * h->dv.d.Ppad;
+    RLC_HIP(hipMemcpyAsync(h->dv.theta_t + off, h->dv.theta + off, h->dv.d.P * sizeof(float),
+                           hipMemcpyDeviceToDevice, h->st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- replay
+int rlc_replay_add(rlc_ddpg* h, int32_t agent, const double* state, const double* action, double reward,
+                   const double* next_state, double transition_gamma) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(state && action && next_state, "null transition field");
+    const int S = h->dv.d.S, A = h->dv.d.A;
+    if (2 * S + A > RLC_PUT1_MAX_FLOATS)
+        return rlc_replay_add_batch(h, agent, 1, state, action, &reward, next_state, &transition_gamma);
+    RlcRingMeta& m = h->ring[agent];
+    RlcPut1 t;
+    for (int i = 0; i < S; i++) { t.sas[i] = (float)state[i]; t.sas[S + i] = (float)next_state[i]; }
+    for (int j = 0; j < A; j++) t.sas[2 * S + j] = (float)action[j];
+    t.r = reward;
+    t.g = transition_gamma;
+    // append on the right; when full the oldest (left) is evicted (custom_collections.py:83-101)
+    t.slot = (m.start + m.size) % h->dv.cap;
+    if (m.size == h->dv.cap) m.start = (m.start + 1) % h->dv.cap;
+    else m.size += 1;
+    t.new_start = m.start;
+    t.new_size = m.size;
+    return rlc_launch_replay_put1(h->dv, agent, t, h->st);
+}
+
+int rlc_replay_add_batch(rlc_ddpg* h, int32_t agent, int64_t n, const double* states, const double* actions,
+                         const double* rewards, const double* next_states, const double* gammas) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(n >= 0, "negative count");
+    if (n == 0) return 0;
+    RLC_REQUIRE(states && actions && rewards && next_states && gammas, "null transition field");
+    const size_t S = h->dv.d.S, A = h->dv.d.A;
+    const long long cap = h->dv.cap;
+    // only the newest `cap` of a longer batch can survive FIFO eviction
+    long long skip = n > cap ? n - cap : 0;
+    const long long m_eff = n - skip;
+    const size_t fbytes = sizeof(float) * m_eff * (2 * S + A);
+    const size_t dbytes = sizeof(double) * m_eff * 2;
+    if (ensure_io(h, fbytes + dbytes + 64)) return 1;
+    RLC_HIP(hipStreamSynchronize(h->st));
+    double* hd = (double*)h->io_host;                 // doubles first (8-byte alignment)
+    float* hf = (float*)(hd + 2 * m_eff);
+    for (long long i = 0; i < m_eff; i++) {
+        hd[i] = rewards[skip + i];
+        hd[m_eff + i] = gammas[skip + i];
+    }
+    float* hs = hf; float* hs2 = hf + m_eff * S; float* ha = hf + 2 * m_eff * S;
+    for (size_t i = 0; i < (size_t)m_eff * S; i++) { hs[i] = (float)states[skip * S + i]; hs2[i] = (float)next_states[skip * S + i]; }
+    for (size_t i = 0; i < (size_t)m_eff * A; i++) ha[i] = (float)actions[skip * A + i];
+    RLC_HIP(hipMemcpyAsync(h->io_dev, h->io_host, dbytes + fbytes, hipMemcpyHostToDevice, h->st));
+    double* dd = (double*)h->io_dev;
+    float* df = (float*)(dd + 2 * m_eff);
+    RlcRingMeta& m = h->ring[agent];
+    // state after `skip` virtual appends followed by m_eff real ones
+    long long start = m.start, size = m.size;
+    auto advance = [&](long long k) {
+        const long long room = cap - size;
+        const long long grow = k < room ? k : room;
+        size += grow;
+        start = (start + (k - grow)) % cap;
+    };
+    advance(skip);
+    const long long first_slot = (start + size) % cap;   // == start when full
+    advance(m_eff);
+    if (rlc_launch_replay_scatter(h->dv, agent, first_slot, m_eff, df, df + 2 * m_eff * S, dd, df + m_eff * S,
+                                  dd + m_eff, h->st))
+        return 1;
+    m.start = start; m.size = size;
+    if (rlc_launch_set_ring(h->dv, agent, start, size, h->st)) return 1;
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_replay_fill_all_dev(rlc_ddpg* h, int64_t n, const float* s_dev, const float* a_dev, const double* r_dev,
+                            const float* s2_dev, const double* g_dev) {
+    RLC_REQUIRE(h, "null handle");
+    if (use_device(h)) return 1;
+    RLC_REQUIRE(n >= 1 && n <= h->dv.cap, "fill count %lld outside [1, capacity %lld]", (long long)n, h->dv.cap);
+    RLC_REQUIRE(s_dev && a_dev && r_dev && s2_dev && g_dev, "null device array");
+    if (rlc_launch_replay_fill_all(h->dv, n, s_dev, a_dev, r_dev, s2_dev, g_dev, h->st)) return 1;
+    for (auto& m : h->ring) { m.start = 0; m.size = n; }
+    return 0;
+}
+
+int rlc_replay_size(const rlc_ddpg* h, int32_t agent, int64_t* out_size) {
+    if (check_agent(h, agent)) return 2;
+    RLC_REQUIRE(out_size, "null out_size");
+    *out_size = h->ring[agent].size;
+    return 0;
+}
+
+int rlc_replay_gather(rlc_ddpg* h, int32_t agent, const int64_t* logical_idx, int32_t k, double* states,
+                      double* actions, double* rewards, double* next_states, double* gammas) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(k >= 0, "negative k");
+    if (k == 0) return 0;
+    RLC_REQUIRE(logical_idx && states && actions && rewards && next_states && gammas, "null array");
+    const long long size = h->ring[agent].size;
+    for (int i = 0; i < k; i++)
+        RLC_REQUIRE(logical_idx[i] >= 0 && logical_idx[i] < size, "RandomAccessQueue index out of range: %lld (size %lld)",
+                    (long long)logical_idx[i], size);
+    const size_t S = h->dv.d.S, A = h->dv.d.A;
+    const size_t ibytes = sizeof(long long) * k, dbytes = sizeof(double) * 2 * k, fbytes = sizeof(float) * k * (2 * S + A);
+    if (ensure_io(h, ibytes + dbytes + fbytes)) return 1;
+    RLC_HIP(hipStreamSynchronize(h->st));
+    long long* di = (long long*)h->io_dev;
+    double* dd = (double*)(di + k);
+    float* df = (float*)(dd + 2 * k);
+    memcpy(h->io_host, logical_idx, ibytes);
+    RLC_HIP(hipMemcpyAsync(di, h->io_host, ibytes, hipMemcpyHostToDevice, h->st));
+    if (rlc_launch_replay_gather(h->dv, agent, di, k, df, df + 2 * k * S, dd, df + k * S, dd + k, h->st)) return 1;
+    RLC_HIP(hipMemcpyAsync(h->io_host, h->io_dev, ibytes + dbytes + fbytes, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    const double* hd = (const double*)((const long long*)h->io_host + k);
+    const float* hf = (const float*)(hd + 2 * k);
+    for (size_t i = 0; i < (size_t)k * S; i++) { states[i] = hf[i]; next_states[i] = hf[k * S + i]; }
+    for (size_t i = 0; i < (size_t)k * A; i++) actions[i] = hf[2 * k * S + i];
+    for (int i = 0; i < k; i++) { rewards[i] = hd[i]; gammas[i] = hd[k + i]; }
+    return 0;
+}
+
+int rlc_replay_sample_indices(rlc_ddpg* h, int32_t agent, int32_t k, int64_t* out_idx) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    const long long size = h->ring[agent].size;
+    // utils/custom_collections.py:110-111
+    RLC_REQUIRE(k >= 0 && k <= size, "Sample larger than population or is negative (k=%d, n=%lld)", k, size);
+    RLC_REQUIRE(k <= RLC_MAX_BATCH, "k=%d exceeds RLC_MAX_BATCH=%d", k, RLC_MAX_BATCH);
+    if (k == 0) return 0;
+    RLC_REQUIRE(out_idx, "null out_idx");
+    if (ensure_io(h, sizeof(long long) * k)) return 1;
+    if (rlc_launch_sample_indices(h->dv, agent, k, (long long*)h->io_dev, h->st)) return 1;
+    RLC_HIP(hipMemcpyAsync(out_idx, h->io_dev, sizeof(long long) * k, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------- acting
+static int act_common(rlc_ddpg* h, int first_agent, int n, const double* states, float* out_actions, int explore) {
+    RLC_REQUIRE(h, "null handle");
+    if (use_device(h)) return 1;
+    RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->dv.n_agents, "agent range [%d,%d) invalid",
+                first_agent, first_agent + n);
+    RLC_REQUIRE(states && out_actions, "null array");
+    const size_t S = h->dv.d.S, A = h->dv.d.A;
+    const size_t in_b = sizeof(float) * n * S, out_b = sizeof(float) * n * A;
+    if (ensure_io(h, in_b + out_b)) return 1;
+    float* hin = (float*)h->io_host;
+    for (size_t i = 0; i < (size_t)n * S; i++) hin[i] = (float)states[i];
+    float* din = h->io_dev;
+    float* dout = h->io_dev + n * S;
+    RLC_HIP(hipMemcpyAsync(din, hin, in_b, hipMemcpyHostToDevice, h->st));
+    if (rlc_launch_act(h->dv, first_agent, n, din, dout, explore, h->st)) return 1;
+    RLC_HIP(hipMemcpyAsync(hin + n * S, dout, out_b, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    memcpy(out_actions, hin + n * S, out_b);
+    return 0;
+}
+
+int rlc_ddpg_act(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions) {
+    return act_common(h, first_agent, n, states, out_actions, 0);
+}
+
+int rlc_ddpg_act_explore(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions) {
+    return act_common(h, first_agent, n, states, out_actions, 1);
+}
+
+int rlc_ddpg_reset_noise(rlc_ddpg* h, int32_t first_agent, int32_t n) {
+    RLC_REQUIRE(h, "null handle");
+    if (use_device(h)) return 1;
+    RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->dv.n_agents, "agent range invalid");
+    return rlc_launch_reset_noise(h->dv, first_agent, n, h->st);
+}
+
+int rlc_ddpg_qval(rlc_ddpg* h, int32_t agent, int32_t n, const double* states, const double* actions, float* out_q) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(n >= 1 && states && actions && out_q, "bad arguments");
+    const size_t S = h->dv.d.S, A = h->dv.d.A;
+    const size_t in_b = sizeof(float) * n * (S + A), out_b = sizeof(float) * n;
+    if (ensure_io(h, in_b + out_b)) return 1;
+    float* hin = (float*)h->io_host;
+    for (size_t i = 0; i < (size_t)n * S; i++) hin[i] = (float)states[i];
+    for (size_t i = 0; i < (size_t)n * A; i++) hin[n * S + i] = (float)actions[i];
+    RLC_HIP(hipMemcpyAsync(h->io_dev, hin, in_b, hipMemcpyHostToDevice, h->st));
+    float* dout = h->io_dev + n * (S + A);
+    if (rlc_launch_qval(h->dv, agent, n, h->io_dev, h->io_dev + n * S, dout, h->st)) return 1;
+    RLC_HIP(hipMemcpyAsync(hin + n * (S + A), dout, out_b, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    memcpy(out_q, hin + n * (S + A), out_b);
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------- learning
+static int pick_variant(const rlc_ddpg* h) {
+    if (h->variant == 1) return 1;
+    if (h->variant == 2) return 2;
+    return rlc_mfma_supported(h->dv.d) ? 2 : 1;
+}
+
+static int launch_update(rlc_ddpg* h, int first, int n, int n_updates, int source, const long long* idx_dev) {
+    const int v = pick_variant(h);
+    if (v == 2) {
+        RLC_REQUIRE(rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
+        return rlc_launch_ddpg_update_mfma(h->dv, first, n, n_updates, source, idx_dev, h->grad_taps, h->st);
+    }
+    return rlc_launch_ddpg_update_generic(h->dv, first, n, n_updates, source, idx_dev, h->grad_taps, h->st);
+}
+
+int rlc_ddpg_update(rlc_ddpg* h, int32_t n_updates, const int64_t* host_indices) {
+    RLC_REQUIRE(h, "null handle");
+    if (use_device(h)) return 1;
+    RLC_REQUIRE(n_updates >= 0, "negative n_updates");
+    if (n_updates == 0) return 0;
+    const int B = h->dv.d.B, NA = h->dv.n_agents;
+    for (int a = 0; a < NA; a++)   // utils/replaybuffer.py:34
+        RLC_REQUIRE(h->ring[a].size >= B, "agent %d: replay holds %lld transitions < batch_size %d", a,
+                    h->ring[a].size, B);
+    int source = RLC_SRC_REPLAY_DEVICE_SAMPLER;
+    if (host_indices) {
+        const size_t count = (size_t)NA * n_updates * B;
+        for (int a = 0; a < NA; a++) {
+            const long long size = h->ring[a].size;
+            const int64_t* p = host_indices + (size_t)a * n_updates * B;
+            for (size_t i = 0; i < (size_t)n_updates * B; i++)
+                RLC_REQUIRE(p[i] >= 0 && p[i] < size, "agent %d: sample index %lld out of range (size %lld)", a,
+                            (long long)p[i], size);
+        }
+        if (count > h->idx_cap) {
+            RLC_HIP(hipStreamSynchronize(h->st));
+            if (h->idx_dev) RLC_HIP(hipFree(h->idx_dev));
+            h->idx_dev = nullptr; h->idx_cap = 0;
+            RLC_HIP(hipMalloc((void**)&h->idx_dev, sizeof(long long) * count * 2));
+            h->idx_cap = count * 2;
+        }
+        RLC_HIP(hipMemcpyAsync(h->idx_dev, host_indices, sizeof(long long) * count, hipMemcpyHostToDevice, h->st));
+        source = RLC_SRC_REPLAY_HOST_INDICES;
+    }
+    return launch_update(h, 0, NA, n_updates, source, h->idx_dev);
+}
+
+int rlc_ddpg_update_batch(rlc_ddpg* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+                          const double* next_states, const double* rewards, const double* gammas) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(batch == h->dv.d.B, "minibatch has %d rows; the handle was created for batch_size %d", batch, h->dv.d.B);
+    RLC_REQUIRE(states && actions && next_states && rewards && gammas, "null minibatch array");
+    const size_t S = h->dv.d.S, A = h->dv.d.A, B = batch;
+    const size_t fbytes = sizeof(float) * B * (2 * S + A), dbytes = sizeof(double) * 2 * B;
+    if (ensure_io(h, fbytes + dbytes)) return 1;
+    RLC_HIP(hipStreamSynchronize(h->st));
+    double* hd = (double*)h->io_host;
+    float* hf = (float*)(hd + 2 * B);
+    for (size_t i = 0; i < B; i++) { hd[i] = rewards[i]; hd[B + i] = gammas[i]; }
+    for (size_t i = 0; i < B * S; i++) { hf[i] = (float)states[i]; hf[B * S + i] = (float)next_states[i]; }
+    for (size_t i = 0; i < B * A; i++) hf[2 * B * S + i] = (float)actions[i];
+    const size_t slot = (size_t)agent * RLC_MAX_BATCH;
+    RLC_HIP(hipMemcpyAsync(h->dv.gr + slot, hd, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->dv.gg + slot, hd + B, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->dv.gs + slot * S, hf, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->dv.gs2 + slot * S, hf + B * S, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->dv.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
+    return launch_update(h, agent, 1, 1, RLC_SRC_STAGING, nullptr);
+}
+
+int rlc_ddpg_set_kernel(rlc_ddpg* h, int32_t variant) {
+    RLC_REQUIRE(h, "null handle");
+    RLC_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (auto), 1 (generic) or 2 (mfma)");
+    RLC_REQUIRE(variant != 2 || rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
+    h->variant = variant;
+    return 0;
+}
+
+int rlc_ddpg_get_kernel(const rlc_ddpg* h, int32_t* variant_in_use) {
+    RLC_REQUIRE(h && variant_in_use, "null argument");
+    *variant_in_use = pick_variant(h);
+    return 0;
+}
+
+int rlc_ddpg_last_tap(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+    if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_REQUIRE(dst, "null dst");
+    const int B = h->dv.d.B, A = h->dv.d.A, P = h->dv.d.P;
+    const float* src = nullptr;
+    long long want = 0;
+    switch (which) {
+        case 0: src = h->dv.tap_q + (size_t)agent * RLC_MAX_BATCH; want = B; break;
+        case 1: src = h->dv.tap_y + (size_t)agent * RLC_MAX_BATCH; want = B; break;
+        case 2: src = h->dv.tap_aout + (size_t)agent * RLC_MAX_BATCH * A; want = (long long)B * A; break;
+        case 3: src = h->dv.tap_dqda + (size_t)agent * RLC_MAX_BATCH * A; want = (long long)B * A; break;
+        case 4: src = h->dv.tap_gc ? h->dv.tap_gc + (size_t)agent * h->dv.d.Ppad : nullptr; want = P; break;
+        case 5: src = h->dv.tap_ga ? h->dv.tap_ga + (size_t)agent * h->dv.d.Ppad : nullptr; want = P; break;
+        default: break;
+    }
+    RLC_REQUIRE(src, "tap %d not available (gradient taps need rlc_ddpg_enable_grad_taps)", which);
+    RLC_REQUIRE(n == want, "tap %d holds %lld floats, caller asked for %lld", which, want, (long long)n);
+    RLC_HIP(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_ddpg_enable_grad_taps(rlc_ddpg* h, int32_t on) {
+    RLC_REQUIRE(h, "null handle");
+    if (use_device(h)) return 1;
+    if (on && !h->dv.tap_gc) {
+        const size_t n = (size_t)h->dv.n_agents * h->dv.d.Ppad;
+        if (dmalloc(h, &h->dv.tap_gc, n)) return 1;
+        if (dmalloc(h, &h->dv.tap_ga, n)) return 1;
+    }
+    h->grad_taps = on ? 1 : 0;
+    return 0;
+}
+
+int rlc_timer_begin(rlc_ddpg* h) {
+    RLC_REQUIRE(h, "null handle");
+    if (use_device(h)) return 1;
+    RLC_HIP(hipEventRecord(h->ev0, h->st));
+    return 0;
+}
+
+int rlc_timer_end(rlc_ddpg* h, float* out_ms) {
+    RLC_REQUIRE(h && out_ms, "null argument");
+    if (use_device(h)) return 1;
+    RLC_HIP(hipEventRecord(h->ev1, h->st));
+    RLC_HIP(hipEventSynchronize(h->ev1));
+    RLC_HIP(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// rlc_common.h -- shared host/device declarations of librlcontrol_hip.so (gfx950 only).
+// Product code: never includes or links anything from oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rlcontrol_hip.h"
+
+#define RLC_MAX_BATCH 128      // minibatch rows per update (LDS-resident per-sample vectors)
+#define RLC_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: every ABI entry returns 0 / non-zero and leaves a message for rlc_last_error()
+// ---------------------------------------------------------------------------------------------
+void rlc_set_error(const char* fmt, ...);
+
+#define RLC_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (call);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            rlc_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return 1;                                                                          \
+        }                                                                                      \
+    } while (0)
+
+#define RLC_REQUIRE(cond, ...)        \
+    do {                              \
+        if (!(cond)) {                \
+            rlc_set_error(__VA_ARGS__); \
+            return 2;                 \
+        }                             \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// network geometry.  Blob layout = variable creation order of hydra_ddpg_network.py:100-140.
+// ---------------------------------------------------------------------------------------------
+struct RlcDims {
+    int S, A, H1, HA, HC, B;
+    int oW1, ob1, oWa2, oba2, oWa3, oba3, oWc2, obc2, oWc3, obc3;
+    int P;      // parameter count
+    int Ppad;   // per-agent stride of every blob (P rounded up to 64 floats = 256 B)
+};
+
+inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B) {
+    RlcDims d;
+    d.S = S; d.A = A; d.H1 = H1; d.HA = HA; d.HC = HC; d.B = B;
+    int p = 0;
+    d.oW1 = p;  p += S * H1;
+    d.ob1 = p;  p += H1;
+    d.oWa2 = p; p += H1 * HA;
+    d.oba2 = p; p += HA;
+    d.oWa3 = p; p += HA * A;
+    d.oba3 = p; p += A;
+    d.oWc2 = p; p += (H1 + A) * HC;
+    d.obc2 = p; p += HC;
+    d.oWc3 = p; p += HC;
+    d.obc3 = p; p += 1;
+    d.P = p;
+    d.Ppad = (p + 63) & ~63;
+    return d;
+}
+
+// Replay ring of ONE agent lives at agent*cap inside each SoA array.  Logical index 0 = oldest.
+struct RlcRingMeta {
+    long long start;   // physical slot of the oldest transition
+    long long size;    // number stored (<= cap)
+};
+
+// Everything a kernel needs; passed by value as a kernel argument (all pointers are device memory).
+struct RlcDev {
+    RlcDims d;
+    int n_agents;
+    long long cap;               // replay capacity per agent
+    int clip_state;
+    float tau;
+    float ou_theta, ou_mu, ou_sigma;
+    // networks + optimizer state: [n_agents][Ppad]
+    float *theta, *theta_t, *m_a, *v_a, *m_c, *v_c;
+    float* pw;                   // [n_agents][4] beta powers {a1,a2,c1,c2}
+    const float *actor_lr, *critic_lr;   // [n_agents]
+    const float *smin, *smax, *amin, *amax;
+    // replay SoA: [n_agents][cap][*]
+    float* rs; float* ra; double* rr; float* rs2; double* rg;
+    RlcRingMeta* ring;           // [n_agents]
+    // staging minibatch (update_batch): [n_agents][RLC_MAX_BATCH][*]
+    float* gs; float* ga; double* gr; float* gs2; double* gg;
+    // device RNG
+    const unsigned long long* seed;      // [n_agents] Philox keys
+    unsigned long long* sample_ctr;      // [n_agents] sampler invocations so far
+    unsigned long long* noise_ctr;       // [n_agents] OU draws so far
+    float* ou_state;                     // [n_agents][A]
+    // taps of the last update: [n_agents][B], [B], [B*A], [B*A]; grads [n_agents][Ppad] (optional)
+    float *tap_q, *tap_y, *tap_aout, *tap_dqda, *tap_gc, *tap_ga;
+    // generic-kernel scratch: [n_agents][scratch_stride] floats
+    float* scratch;
+    long long scratch_stride;
+};
+
+// where a launch takes its minibatch from
+enum RlcBatchSource { RLC_SRC_REPLAY_DEVICE_SAMPLER = 0, RLC_SRC_REPLAY_HOST_INDICES = 1, RLC_SRC_STAGING = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// host launchers implemented in the kernel translation units
+// ---------------------------------------------------------------------------------------------
+// generic (any dims) fused update: one workgroup per agent, n_updates sequential updates per launch
+int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                                   const long long* idx_dev, int grad_taps, hipStream_t st);
+// MFMA-tiled fused update (dims must satisfy rlc_mfma_supported)
+bool rlc_mfma_supported(const RlcDims& d);
+int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                                const long long* idx_dev, int grad_taps, hipStream_t st);
+// acting / evaluation
+int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states_dev, float* out_dev, int explore,
+                   hipStream_t st);
+int rlc_launch_qval(const RlcDev& dv, int agent, int n, const float* states_dev, const float* actions_dev,
+                    float* out_dev, hipStream_t st);
+int rlc_launch_reset_noise(const RlcDev& dv, int first_agent, int n, hipStream_t st);
+size_t rlc_generic_scratch_floats(const RlcDims& d);
+// replay
+int rlc_launch_replay_scatter(const RlcDev& dv, int agent, long long first_slot, long long n, const float* s,
+                              const float* a, const double* r, const float* s2, const double* g, hipStream_t st);
+int rlc_launch_replay_fill_all(const RlcDev& dv, long long n, const float* s, const float* a, const double* r,
+                               const float* s2, const double* g, hipStream_t st);
+int rlc_launch_replay_gather(const RlcDev& dv, int agent, const long long* logical_idx_dev, int k, float* s,
+                             float* a, double* r, float* s2, double* g, hipStream_t st);
+int rlc_launch_sample_indices(const RlcDev& dv, int agent, int k, long long* out_idx_dev, hipStream_t st);
+// single transition passed by value (no staging copy): ReplayBuffer.add for one env step
+#define RLC_PUT1_MAX_FLOATS 56
+struct RlcPut1 {
+    float sas[RLC_PUT1_MAX_FLOATS];   // s[S] | s2[S] | a[A]
+    double r, g;
+    long long slot, new_start, new_size;
+};
+int rlc_launch_replay_put1(const RlcDev& dv, int agent, const RlcPut1& t, hipStream_t st);
+int rlc_launch_set_ring(const RlcDev& dv, int agent, long long start, long long size, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// device-side helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// Philox4x32-10 (Salmon et al. 2011): counter-based, one independent stream per (key, counter).
+struct Philox4 { unsigned int x, y, z, w; };
+
+__device__ __forceinline__ Philox4 philox4x32_10(unsigned long long key, unsigned long long ctr_lo,
+                                                 unsigned long long ctr_hi) {
+    unsigned int k0 = (unsigned int)key, k1 = (unsigned int)(key >> 32);
+    unsigned int c0 = (unsigned int)ctr_lo, c1 = (unsigned int)(ctr_lo >> 32);
+    unsigned int c2 = (unsigned int)ctr_hi, c3 = (unsigned int)(ctr_hi >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0;
+        const unsigned int n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        const unsigned int n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+
+// unbiased-enough integer in [0,n): high 64 bits of (64 random bits x n); bias < n / 2^64
+__device__ __forceinline__ long long philox_below(const Philox4& p, long long n) {
+    const unsigned long long u = ((unsigned long long)p.x << 32) | p.y;
+    return (long long)__umul64hi(u, (unsigned long long)n);
+}
+
+// two standard normals from one Philox draw (Box-Muller on (0,1] uniforms)
+__device__ __forceinline__ void philox_normal2(const Philox4& p, float& n0, float& n1) {
+    const float u0 = ((float)(p.x >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+    const float u1 = (float)(p.y >> 8) * (1.0f / 16777216.0f);            // [0,1)
+    const float rad = sqrtf(-2.0f * logf(u0));
+    n0 = rad * cosf(6.28318530717958647692f * u1);
+    n1 = rad * sinf(6.28318530717958647692f * u1);
+}
+
+// logical (0 = oldest) -> physical slot of an agent's ring
+__device__ __forceinline__ long long ring_slot(const RlcRingMeta& m, long long cap, long long logical) {
+    long long p = m.start + logical;
+    return p >= cap ? p - cap : p;
+}
+
+__device__ __forceinline__ float clip_state_val(float v, int do_clip, float lo, float hi) {
+    // hydra_ddpg_network.py:86-87 with RunningMeanStd mean 0 / var 1 baked in (quirk Q6)
+    return do_clip ? fminf(fmaxf((v - 0.0f) / 1.0f, lo), hi) : v;
+}
+
+// TF-1.15 ApplyAdam on one element (core/kernels/training_ops.cc, non-Nesterov; quirk Q2)
+__device__ __forceinline__ float adam_step(float var, float g, float& m, float& v, float alpha) {
+    m += (g - m) * (1.0f - 0.9f);
+    v += (g * g - v) * (1.0f - 0.999f);
+    return var - (m * alpha) / (sqrtf(v) + 1e-8f);
+}
+
+__device__ __forceinline__ float adam_alpha(float lr, float b1p, float b2p) {
+    return lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
+}
+
+// k distinct uniform logical indices in [0, n) for one agent; one workgroup.
+// dense regime (3k >= n, as in sample_n_k): partial Fisher-Yates over an LDS copy of range(n);
+// sparse regime: one candidate per thread, duplicates (against lower-numbered threads) redrawn
+// until none remain -- equivalent in distribution to sequential sampling without replacement.
+__device__ inline void rlc_sample_distinct(long long n, int k, unsigned long long key, unsigned long long call,
+                                           int* lds_pool /* >= 3*RLC_MAX_BATCH ints */, long long* out /* LDS, k */,
+                                           int* lds_dups /* 1 int */) {
+    const int tid = threadIdx.x;
+    if (3LL * k >= n) {
+        for (int i = tid; i < (int)n; i += blockDim.x) lds_pool[i] = i;
+        __syncthreads();
+        if (tid == 0) {
+            for (int i = 0; i < k; i++) {
+                const Philox4 p = philox4x32_10(key, call, 0x100000000ull + (unsigned long long)i);
+                const int j = i + (int)philox_below(p, n - i);
+                const int t = lds_pool[i]; lds_pool[i] = lds_pool[j]; lds_pool[j] = t;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < k; i += blockDim.x) out[i] = lds_pool[i];
+        __syncthreads();
+        return;
+    }
+    long long mine = -1;
+    unsigned int round = 0;
+    bool need = tid < k;
+    for (;;) {
+        if (need) {
+            const Philox4 p = philox4x32_10(key, call, ((unsigned long long)round << 32) | (unsigned int)tid);
+            mine = philox_below(p, n);
+            out[tid] = mine;
+        }
+        if (tid == 0) *lds_dups = 0;
+        __syncthreads();
+        need = false;
+        if (tid < k) {
+            for (int j = 0; j < tid; j++)
+                if (out[j] == mine) { need = true; break; }
+            if (need) atomicAdd(lds_dups, 1);
+        }
+        __syncthreads();
+        const int dups = *lds_dups;
+        __syncthreads();
+        if (dups == 0) break;
+        round++;
+    }
+}
+
+
+#endif  // __HIPCC__

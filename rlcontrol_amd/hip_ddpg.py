@@ -1,0 +1,225 @@
+"""Python face of one ``rlc_ddpg`` handle: a population of independent DDPG agents on one MI355X.
+
+Thin, typed wrappers over the C ABI (include/rlcontrol_hip.h); no arithmetic happens here.
+``n_agents == 1`` is the reference's one-agent-per-process deployment (main.py:111-185); larger
+populations are the reference's INDEX sweep (settings x seeds) co-resident on one GPU.
+"""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, dptr, f64, fptr, iptr
+
+
+def param_layout(S, A, H1, HA, HC):
+    """name -> (offset, shape), creation order of hydra_ddpg_network.py:100-140."""
+    out = OrderedDict()
+    p = 0
+    for name, shp in (("W1", (S, H1)), ("b1", (H1,)), ("Wa2", (H1, HA)), ("ba2", (HA,)),
+                      ("Wa3", (HA, A)), ("ba3", (A,)), ("Wc2", (H1 + A, HC)), ("bc2", (HC,)),
+                      ("Wc3", (HC, 1)), ("bc3", (1,))):
+        out[name] = (p, shp)
+        p += int(np.prod(shp))
+    return out, p
+
+
+def init_params(S, A, H1, HA, HC, seed):
+    """Initial weights with the reference's initialiser families (hydra_ddpg_network.py:101-140):
+    hidden W and b ~ U(+-sqrt(3/fan_in)) (variance_scaling_initializer(factor=1, FAN_IN, uniform);
+    for a 1-D bias [n] TF takes fan_in = n), output-layer W, b ~ U(+-3e-3).  TensorFlow's own
+    Philox stream under tf.set_random_seed(seed) (agents/DDPG.py:21) cannot be reproduced without
+    TensorFlow, so the draws come from numpy RandomState(seed): same distributions, different
+    numbers ("parity unpinned")."""
+    rng = np.random.RandomState(seed)
+    lay, P = param_layout(S, A, H1, HA, HC)
+    theta = np.zeros(P, np.float32)
+    for name, (off, shp) in lay.items():
+        n = int(np.prod(shp))
+        lim = 3e-3 if name in ("Wa3", "ba3", "Wc3", "bc3") else np.sqrt(3.0 / shp[0])
+        theta[off:off + n] = rng.uniform(-lim, lim, n).astype(np.float32)
+    return theta
+
+
+class DDPGPopulation(object):
+    BLOB = {"theta": 0, "theta_target": 1, "actor_m": 2, "actor_v": 3, "critic_m": 4, "critic_v": 5}
+    TAP = {"q": 0, "y": 1, "a_out": 2, "dqda": 3, "grads_c": 4, "grads_a": 5}
+    KERNEL = {"auto": 0, "generic": 1, "mfma": 2}
+
+    def __init__(self, n_agents, state_dim, action_dim, shared_l1_dim, actor_l2_dim, critic_l2_dim, batch_size,
+                 buffer_size, tau, state_min, state_max, action_min, action_max, actor_lr, critic_lr, seeds,
+                 clip_state=True, ou_theta=0.15, ou_mu=0.0, ou_sigma=0.2, device=0):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.n_agents = int(n_agents)
+        self.S, self.A = int(state_dim), int(action_dim)
+        self.H1, self.HA, self.HC = int(shared_l1_dim), int(actor_l2_dim), int(critic_l2_dim)
+        self.B = int(batch_size)
+        self.layout, self.P = param_layout(self.S, self.A, self.H1, self.HA, self.HC)
+        bc = lambda v, n: np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32).reshape(-1), (n,)))
+        self._keep = dict(
+            smin=bc(state_min, self.S), smax=bc(state_max, self.S), amin=bc(action_min, self.A),
+            amax=bc(action_max, self.A), lra=bc(actor_lr, self.n_agents), lrc=bc(critic_lr, self.n_agents),
+            seed=np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, np.uint64).reshape(-1), (self.n_agents,))))
+        cfg = _lib.rlc_ddpg_config()
+        cfg.device = int(device)
+        cfg.n_agents = self.n_agents
+        cfg.state_dim, cfg.action_dim = self.S, self.A
+        cfg.shared_l1_dim, cfg.actor_l2_dim, cfg.critic_l2_dim = self.H1, self.HA, self.HC
+        cfg.batch_size = self.B
+        cfg.buffer_size = int(buffer_size)
+        cfg.clip_state = 1 if clip_state else 0
+        cfg.tau = float(tau)
+        cfg.state_min, cfg.state_max = fptr(self._keep["smin"]), fptr(self._keep["smax"])
+        cfg.action_min, cfg.action_max = fptr(self._keep["amin"]), fptr(self._keep["amax"])
+        cfg.actor_lr, cfg.critic_lr = fptr(self._keep["lra"]), fptr(self._keep["lrc"])
+        cfg.seed = self._keep["seed"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+        cfg.ou_theta, cfg.ou_mu, cfg.ou_sigma = float(ou_theta), float(ou_mu), float(ou_sigma)
+        check(self._lib.rlc_ddpg_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+
+    # ---- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rlc_ddpg_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self._lib.rlc_ddpg_sync(self._h))
+
+    # ---- parameters -----------------------------------------------------------------------
+    def set_blob(self, agent, which, values):
+        v = np.ascontiguousarray(values, np.float32).reshape(-1)
+        check(self._lib.rlc_ddpg_set_blob(self._h, int(agent), self.BLOB[which], fptr(v), ctypes.c_int64(v.size)))
+
+    def get_blob(self, agent, which):
+        out = np.empty(self.P, np.float32)
+        check(self._lib.rlc_ddpg_get_blob(self._h, int(agent), self.BLOB[which], fptr(out), ctypes.c_int64(self.P)))
+        return out
+
+    def set_params(self, agent, theta, init_target=True):
+        self.set_blob(agent, "theta", theta)
+        if init_target:
+            check(self._lib.rlc_ddpg_init_target(self._h, int(agent)))
+
+    def get_beta_powers(self, agent):
+        out = np.empty(4, np.float32)
+        check(self._lib.rlc_ddpg_get_beta_powers(self._h, int(agent), fptr(out)))
+        return out
+
+    def set_beta_powers(self, agent, pw4):
+        v = np.ascontiguousarray(pw4, np.float32).reshape(4)
+        check(self._lib.rlc_ddpg_set_beta_powers(self._h, int(agent), fptr(v)))
+
+    def named(self, blob):
+        return OrderedDict((k, blob[o:o + int(np.prod(s))].reshape(s)) for k, (o, s) in self.layout.items())
+
+    # ---- replay ---------------------------------------------------------------------------
+    def replay_add(self, agent, state, action, reward, next_state, transition_gamma):
+        s, a, s2 = f64(state).reshape(-1), f64(action).reshape(-1), f64(next_state).reshape(-1)
+        if s.size != self.S or s2.size != self.S or a.size != self.A:
+            raise ValueError("transition shapes do not match state_dim/action_dim")
+        check(self._lib.rlc_replay_add(self._h, int(agent), dptr(s), dptr(a), ctypes.c_double(float(reward)),
+                                       dptr(s2), ctypes.c_double(float(transition_gamma))))
+
+    def replay_add_batch(self, agent, states, actions, rewards, next_states, gammas):
+        r = f64(rewards).reshape(-1)
+        n = r.size
+        s, s2 = f64(states).reshape(n, self.S), f64(next_states).reshape(n, self.S)
+        a, g = f64(actions).reshape(n, self.A), f64(gammas).reshape(n)
+        check(self._lib.rlc_replay_add_batch(self._h, int(agent), ctypes.c_int64(n), dptr(s), dptr(a), dptr(r),
+                                             dptr(s2), dptr(g)))
+
+    def replay_fill_all_dev(self, n, s_ptr, a_ptr, r_ptr, s2_ptr, g_ptr):
+        """device pointers (ints), e.g. torch tensor .data_ptr(): fp32 s/a/s2, fp64 r/gamma"""
+        vp = ctypes.c_void_p
+        check(self._lib.rlc_replay_fill_all_dev(self._h, ctypes.c_int64(int(n)), vp(s_ptr), vp(a_ptr), vp(r_ptr),
+                                                vp(s2_ptr), vp(g_ptr)))
+
+    def replay_size(self, agent):
+        out = ctypes.c_int64(0)
+        check(self._lib.rlc_replay_size(self._h, int(agent), ctypes.byref(out)))
+        return int(out.value)
+
+    def replay_gather(self, agent, logical_idx):
+        idx = np.ascontiguousarray(logical_idx, np.int64).reshape(-1)
+        k = idx.size
+        s, s2 = np.empty((k, self.S)), np.empty((k, self.S))
+        a, r, g = np.empty((k, self.A)), np.empty(k), np.empty(k)
+        check(self._lib.rlc_replay_gather(self._h, int(agent), iptr(idx), ctypes.c_int32(k), dptr(s), dptr(a),
+                                          dptr(r), dptr(s2), dptr(g)))
+        return s, a, r, s2, g
+
+    def replay_sample_indices(self, agent, k):
+        out = np.empty(int(k), np.int64)
+        check(self._lib.rlc_replay_sample_indices(self._h, int(agent), ctypes.c_int32(int(k)), iptr(out)))
+        return out
+
+    # ---- acting ---------------------------------------------------------------------------
+    def act(self, states, first_agent=0, explore=False):
+        s = f64(states).reshape(-1, self.S)
+        out = np.empty((s.shape[0], self.A), np.float32)
+        fn = self._lib.rlc_ddpg_act_explore if explore else self._lib.rlc_ddpg_act
+        check(fn(self._h, int(first_agent), ctypes.c_int32(s.shape[0]), dptr(s), fptr(out)))
+        return out
+
+    def reset_noise(self, first_agent=0, n=None):
+        check(self._lib.rlc_ddpg_reset_noise(self._h, int(first_agent), int(self.n_agents if n is None else n)))
+
+    def qval(self, agent, states, actions):
+        s = f64(states).reshape(-1, self.S)
+        a = f64(actions).reshape(-1, self.A)
+        out = np.empty(s.shape[0], np.float32)
+        check(self._lib.rlc_ddpg_qval(self._h, int(agent), ctypes.c_int32(s.shape[0]), dptr(s), dptr(a), fptr(out)))
+        return out
+
+    # ---- learning -------------------------------------------------------------------------
+    def update(self, n_updates=1, host_indices=None):
+        if host_indices is None:
+            check(self._lib.rlc_ddpg_update(self._h, ctypes.c_int32(int(n_updates)), None))
+            return
+        idx = np.ascontiguousarray(host_indices, np.int64)
+        if idx.size != self.n_agents * int(n_updates) * self.B:
+            raise ValueError("host_indices must hold n_agents*n_updates*batch_size entries")
+        check(self._lib.rlc_ddpg_update(self._h, ctypes.c_int32(int(n_updates)), iptr(idx)))
+
+    def update_batch(self, agent, states, actions, next_states, rewards, gammas):
+        r = f64(rewards).reshape(-1)
+        n = r.size
+        s, s2 = f64(states).reshape(n, self.S), f64(next_states).reshape(n, self.S)
+        a, g = f64(actions).reshape(n, self.A), f64(gammas).reshape(n)
+        check(self._lib.rlc_ddpg_update_batch(self._h, int(agent), ctypes.c_int32(n), dptr(s), dptr(a), dptr(s2),
+                                              dptr(r), dptr(g)))
+
+    def set_kernel(self, name):
+        check(self._lib.rlc_ddpg_set_kernel(self._h, self.KERNEL[name]))
+
+    def kernel_in_use(self):
+        out = ctypes.c_int32(0)
+        check(self._lib.rlc_ddpg_get_kernel(self._h, ctypes.byref(out)))
+        return {v: k for k, v in self.KERNEL.items()}[out.value]
+
+    def enable_grad_taps(self, on=True):
+        check(self._lib.rlc_ddpg_enable_grad_taps(self._h, 1 if on else 0))
+
+    def last_tap(self, agent, which):
+        n = {"q": self.B, "y": self.B, "a_out": self.B * self.A, "dqda": self.B * self.A,
+             "grads_c": self.P, "grads_a": self.P}[which]
+        out = np.empty(n, np.float32)
+        check(self._lib.rlc_ddpg_last_tap(self._h, int(agent), self.TAP[which], fptr(out), ctypes.c_int64(n)))
+        return out
+
+    # ---- timing ---------------------------------------------------------------------------
+    def timer_begin(self):
+        check(self._lib.rlc_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = ctypes.c_float(0.0)
+        check(self._lib.rlc_timer_end(self._h, ctypes.byref(ms)))
+        return float(ms.value)
