@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py -- DDPG gradient updates/sec/GPU on synthetic Pendulum-shaped replay (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W [--agents A] [--updates-per-step U]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload: obs 3, act 1, shared/actor/critic layers 200/200/200,
+batch 100, actor_lr 1e-3, critic_lr 1e-2, tau 0.01; every agent owns a device-resident replay of 1e6
+synthetic Pendulum transitions (gamma_i = 0.99).  One GPU holds A independent agents (the reference's
+INDEX axis: seeds/settings); one "step" = ONE launch of the fused kernel = U updates of every agent,
+each update = device Philox sample of 100 distinct indices + gather + the full update_network
+(target actor/critic, TD target, critic step, actor step, Polyak).  Inputs are resident in HBM before
+the timed region.  value = (N * A * U * K) / max-over-ranks wall time.
+
+Multi-GPU: ranks are independent (different seeds, no data-path collective) -> "scaling": "weak";
+the only collective is an all-gather of one small per-rank result vector after the timed region
+(the episodic-return all-gather of the 8-GPU INDEX sweep).
+
+The JSON line also carries
+  roofline      dominant kernel vs the fp32 matrix-core peak (the binding roof: 27.8 FLOP/B algorithmic
+                intensity > 19.7 ridge), achieved = 73.2 MFLOP x updates per launch / HIP-event launch time
+  roofline_hbm  the same launch priced in algorithmic HBM bytes (2,634,064 B per update) vs 8 TB/s
+  cpu_baseline  the reference-structured CPU port (oracle/) timed on this host, rank 0 at N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+S, A_DIM, H, B = 3, 1, 200, 100
+REPLAY_N = 10 ** 6
+FLOP_PER_UPDATE = 73.2e6          # 366,000 MAC/sample * 2 * 100
+BYTES_PER_UPDATE = 2634064.0      # params+Adam+target read+write, + 3,600 B gather
+PEAK_FP32_MATRIX = 157.3e12       # MI355X_MICROARCH.md: v_mfma_f32_* dense peak = fp32 vector peak
+PEAK_HBM = 8.0e12                 # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def synthetic_pendulum_replay(n, seed=0):
+    rng = np.random.RandomState(seed)
+    th = rng.uniform(-np.pi, np.pi, n)
+    thd = rng.uniform(-8.0, 8.0, n)
+    a = rng.uniform(-2.0, 2.0, n)
+    s = np.stack([np.cos(th), np.sin(th), thd], 1)
+    r = -(th ** 2 + 0.1 * thd ** 2 + 0.001 * a ** 2)
+    thd2 = thd + (-3 * 10.0 / 2 * np.sin(th + np.pi) + 3.0 * a) * 0.05
+    th2 = th + thd2 * 0.05
+    thd2 = np.clip(thd2, -8.0, 8.0)
+    s2 = np.stack([np.cos(th2), np.sin(th2), thd2], 1)
+    return (s.astype(np.float32), a[:, None].astype(np.float32), r.astype(np.float64), s2.astype(np.float32),
+            np.full(n, 0.99, np.float64))
+
+
+def cpu_baseline(seconds=15.0, records=200000):
+    """Reference-structured CPU port on a bounded sample (1 core): list-of-records replay + sample_n_k +
+    5 np.array conversions + float64 TD glue + the C restatement of the 7-step update."""
+    from oracle.cpu_baseline import ListReplay, Transition
+    from oracle.ddpg import DDPGOracle, Dims, init_params
+    try:
+        import threadpoolctl
+        threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
+    s, a, r, s2, g = synthetic_pendulum_replay(records, 0)
+    rep = ListReplay(records, 0)
+    for i in range(records):
+        rep.append(Transition(s[i].astype(np.float64), a[i].astype(np.float64), float(r[i]),
+                              s2[i].astype(np.float64), 0.99))
+    d = Dims(S, A_DIM, H, H, H)
+    net = DDPGOracle(d, init_params(d, 0), 1e-3, 1e-2, 0.01, [-1, -1, -8], [1, 1, 8], [2.0])
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        (bs, ba, br, bs2, bg), _ = rep.sample_batch(B)
+        net.update(bs, ba, bs2, br, bg)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "gradient updates/s", "cores": 1, "kind": "port",
+            "sample": "%d updates (%.1f s) on a %d-record list replay; oracle/ddpg_oracle.c + reference-"
+                      "structured host loop; TF-1.15 itself cannot run here" % (n, dt, records)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--agents", type=int, default=256, help="independent agents per GPU")
+    ap.add_argument("--updates-per-step", type=int, default=16, help="updates of every agent per launch")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    if rank == 0 or world == 1:
+        entry.build()
+    if dist is not None:
+        dist.barrier()
+    from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
+
+    NA, U = args.agents, args.updates_per_step
+    # rank r holds INDEX values r*NA .. r*NA+NA-1 of a seeds-only sweep: seed = index
+    seeds = np.arange(rank * NA, (rank + 1) * NA, dtype=np.uint64) + 1
+    pop = DDPGPopulation(NA, S, A_DIM, H, H, H, B, REPLAY_N, 0.01, [-1, -1, -8], [1, 1, 8], [-2.0], [2.0],
+                         1e-3, 1e-2, seeds=seeds, device=local_rank)
+    if args.kernel != "auto":
+        pop.set_kernel(args.kernel)
+    for i in range(NA):
+        pop.set_params(i, init_params(S, A_DIM, H, H, H, int(seeds[i])))
+    # synthetic replay -> HBM (torch is only the allocator/copy engine here), then into every agent's ring
+    host = synthetic_pendulum_replay(REPLAY_N, 0)
+    dev = [torch.from_numpy(x).cuda() for x in host]
+    torch.cuda.synchronize()
+    pop.replay_fill_all_dev(REPLAY_N, dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(),
+                            dev[4].data_ptr())
+    pop.sync()
+    del dev
+
+    def sync_all():
+        pop.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pop.update(U)
+    sync_all()
+    t0 = time.perf_counter()
+    pop.timer_begin()
+    for _ in range(args.steps):
+        pop.update(U)
+    ev_ms = pop.timer_end()
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    result = torch.tensor([float(np.mean(pop.last_tap(0, "q")))], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(result) for _ in range(world)]
+        dist.all_gather(gathered, result)       # the one collective: per-rank results, after the timed region
+    dt_max = float(t.item())
+    kernel = pop.kernel_in_use()
+
+    if rank == 0:
+        updates_per_launch = NA * U
+        launch_s = ev_ms * 1e-3 / args.steps
+        ach_flops = FLOP_PER_UPDATE * updates_per_launch / launch_s
+        ach_bytes = BYTES_PER_UPDATE * updates_per_launch / launch_s
+        out = {
+            "metric": "gradient updates/sec/GPU (batch=100), Pendulum-shaped DDPG",
+            "value": world * NA * U * args.steps / dt_max,
+            "unit": "gradient updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max * 1e3 / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DDPG on synthetic Pendulum-shaped replay (1e6 transitions/agent), obs=3 act=1 "
+                                   "l1=l2=200 batch=100, fused HIP replay-sample+gather+update kernel",
+                       "agents_per_gpu": NA, "updates_per_step": U, "kernel": kernel,
+                       "per_gpu_value": NA * U * args.steps / dt_max,
+                       "parallelism": "independent seeds x%d per GPU, x%d GPUs" % (NA, world)},
+            "roofline": {"bound": "mfma", "achieved": ach_flops / 1e12, "peak": PEAK_FP32_MATRIX / 1e12,
+                         "unit": "TFLOP/s", "frac": ach_flops / PEAK_FP32_MATRIX, "traffic": None,
+                         "kernel_ms_per_launch": launch_s * 1e3, "flop_per_update": FLOP_PER_UPDATE},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                             "frac": ach_bytes / PEAK_HBM, "traffic": None, "bytes_per_update": BYTES_PER_UPDATE},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    pop.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
