@@ -1,32 +1,70 @@
-"""Build librlcontrol_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the tree)."""
+"""Build librlcontrol_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the tree).
+
+Every translation unit is compiled to an object under csrc/_obj/ (in parallel, skipped when newer than
+all sources/headers) and linked into rlcontrol_amd/librlcontrol_hip.so.  The MFMA kernel template is
+instantiated once per (M tiles, action dim) pair, each in its own object.
+"""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(_HERE, "librlcontrol_hip.so")
-SOURCES = ("rlc_api.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result"]
+PLAIN = ("rlc_api.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip")
+MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
-def _deps():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    files.append(os.path.join(_HERE, "..", "include", "rlcontrol_hip.h"))
-    return files
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(_HERE, "..", "include", "rlcontrol_hip.h"))
+    return hs
+
+
+def _units():
+    units = [(os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o")), []) for s in PLAIN]
+    for mt, ad in MFMA_VARIANTS:
+        units.append((os.path.join(CSRC, "ddpg_mfma_inst.hip"), os.path.join(OBJ, "ddpg_mfma_%d_%d.o" % (mt, ad)),
+                      ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
+    return units
+
+
+def _stale(src, obj, hdr_time):
+    return (not os.path.exists(obj)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
 
 
 def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in _deps())
+    srcs = [u[0] for u in _units()] + _headers()
+    return any(os.path.getmtime(f) > t for f in srcs)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, jobs=None):
     if not force and not needs_build():
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in _headers())
+    todo = [u for u in _units() if force or _stale(u[0], u[1], hdr_time)]
+
+    def compile_one(u):
+        src, obj, defs = u
+        cmd = [_hipcc()] + CFLAGS + defs + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, todo))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [u[1] for u in _units()]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -34,4 +72,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         __syncthreads();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
         // ---- step 7: Polyak on all ten tensors (hydra_ddpg_network.py:29) ----
-        for (int p = tid; p < d.P; p += kThreads) {
+        for (int p = tid; p < d.Pdev; p += kThreads) {
             const float t = tt[p];
             tt[p] = t + dv.tau * (th[p] - t);
         }

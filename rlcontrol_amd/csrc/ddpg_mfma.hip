@@ -1,9 +1,34 @@
-// ddpg_mfma.hip -- placeholder until the matrix-core kernel lands (next commit).
-#include "rlc_common.h"
+// ddpg_mfma.hip -- shape check + dispatch to the per-shape instantiations of the MFMA DDPG kernel
+// (kernel: ddpg_mfma_kernel.h; instantiations: ddpg_mfma_inst.hip compiled per (MT, AD)).
+#include "ddpg_mfma_kernel.h"
 
-bool rlc_mfma_supported(const RlcDims&) { return false; }
+#define RLC_DECL(M, A_)                                                                                   \
+    int rlc_mfma_launch_##M##_##A_(const RlcDev&, int, int, int, int, const long long*, int, hipStream_t);
+RLC_DECL(2, 1) RLC_DECL(4, 1) RLC_DECL(7, 1) RLC_DECL(8, 1)
+RLC_DECL(2, 2) RLC_DECL(4, 2) RLC_DECL(7, 2) RLC_DECL(8, 2)
+#undef RLC_DECL
 
-int rlc_launch_ddpg_update_mfma(const RlcDev&, int, int, int, int, const long long*, int, hipStream_t) {
-    rlc_set_error("MFMA kernel not built");
+static inline int mt_for(int B) { return B <= 32 ? 2 : (B <= 64 ? 4 : (B <= 112 ? 7 : 8)); }
+
+bool rlc_mfma_supported(const RlcDims& d) {
+    auto okdim = [](int h) { return h >= 16 && h <= 256 && (h % 4) == 0; };
+    if (!(okdim(d.H1) && okdim(d.HA) && okdim(d.HC))) return false;
+    if (d.S < 1 || d.S > SMAX) return false;
+    if (d.A != 1 && d.A != 2) return false;
+    if (d.B < 1 || d.B > 128) return false;
+    return smem_carve(d, mt_for(d.B), nullptr, nullptr) <= 160 * 1024;
+}
+
+int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                                const long long* idx_dev, int grad_taps, hipStream_t st) {
+    RLC_REQUIRE(rlc_mfma_supported(dv.d), "MFMA kernel does not support these dimensions");
+    const int mt = mt_for(dv.d.B);
+#define RLC_CASE(M, A_)                                                                        \
+    if (mt == M && dv.d.A == A_)                                                               \
+        return rlc_mfma_launch_##M##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st);
+    RLC_CASE(2, 1) RLC_CASE(4, 1) RLC_CASE(7, 1) RLC_CASE(8, 1)
+    RLC_CASE(2, 2) RLC_CASE(4, 2) RLC_CASE(7, 2) RLC_CASE(8, 2)
+#undef RLC_CASE
+    rlc_set_error("no MFMA instantiation for MT=%d A=%d", mt, dv.d.A);
     return 3;
 }

@@ -1,0 +1,820 @@
+// ddpg_mfma.hip -- fused DDPG update on gfx950 fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// Same contract as ddpg_generic.hip (one workgroup per agent, n_updates sequential updates per
+// launch, every update = sample + gather + agents/DDPG.py:74-95), but the nine [B,200]x[200,200]-class
+// contractions of one update run on MFMA tiles and nothing [B,H]-sized ever leaves the CU:
+//
+//   LDS   hbuf   fp32 [MT*16][LDH]   the trunk activation h1 (target / online / post-critic-step), the
+//                                    A operand of every forward GEMM and of both weight-gradient GEMMs
+//         mask16 u16  [MT*16][16]    relu masks of g2 / h2, one bit per unit: dg2 = mask*dq*Wc3 and
+//                                    dh2 = mask*(dz.Wa3) are rank-A outer products, regenerated on the
+//                                    fly as MFMA operands instead of being stored as [B,H] fp32
+//         per-sample vectors (x, x', a, y, q, dq, mu, dz ...), row-reduction partials, a staged Wc3/Wa3
+//   VGPR  accumulators of the GEMM in flight (MT x 4 tiles of 16x16), weight fragments streamed
+//         global -> VGPR (each weight element is read once per GEMM per agent; no LDS staging)
+//   HBM   theta, theta', Adam m/v: Wa2/Wc2 are updated (Adam + Polyak) in the epilogue of their
+//         weight-gradient GEMM straight from the accumulators
+//
+// Tiling: batch rows on the MFMA M axis (MT = ceil(B/16) tiles), features on N; wave w of 8 owns
+// N-tiles w and w+8 for ALL M tiles, so reductions over the batch (bias / W3 / W1 gradients)
+// are wave-local and only reductions over features (q, z, dQ/da) cross waves through LDS partials,
+// summed in a fixed order (deterministic: K updates in one launch == K launches, bit for bit).
+// fp32 in / fp32 accumulate MFMA is a k-ordered fmaf chain (exact fp32), so the 1e-5 parity bar holds.
+//
+// Supported shapes: S <= 8, A in {1,2}, H1/HA/HC multiples of 4 in [16,256], B <= 128.
+#pragma once
+#include "rlc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;     // two waves per SIMD: one can issue MFMA while the other does VALU / waits on loads
+constexpr int NTW = 2;        // N tiles per wave  (N <= 256)
+constexpr int NT16 = 16;      // mask words per row
+constexpr int MC = 7;         // M' tiles per chunk in the weight-gradient GEMMs
+constexpr int SMAX = 8;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// sum over the 16 lanes that share lane>>4 (rotate-reduce with DPP row_ror: every lane gets the sum)
+template <int ROR>
+__device__ __forceinline__ float dpp_ror_add(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + ROR, 0xf, 0xf, false);
+    return x + __int_as_float(y);
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x = dpp_ror_add<8>(x);
+    x = dpp_ror_add<4>(x);
+    x = dpp_ror_add<2>(x);
+    x = dpp_ror_add<1>(x);
+    return x;
+}
+// sum over the 4 lane groups (lanes l, l+16, l+32, l+48)
+__device__ __forceinline__ float col4_sum(float x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+struct Smem {
+    float* hbuf;
+    unsigned short* mask;
+    float* part;      // [kWaves][MB][AD]
+    float* wvec;      // [AD][256] staged Wc3 (row 0) or Wa3 transposed
+    float *x, *x2, *a, *aout, *mu, *dz, *q, *y, *dq;
+    double *r, *g;
+    long long* idx;
+    int* pool;
+    int* dups;
+};
+
+__host__ __device__ inline int ldh_for(int H1) {
+    // leading dimension with (LDH/4) % 16 == 2: conflict-free ds_read_b128 rows AND b32 columns
+    int q = (H1 + 3) / 4;
+    while ((q & 15) != 2) q++;
+    return q * 4;
+}
+
+__host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, unsigned char* base, Smem* out) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = base ? base + off : nullptr;
+        off += (bytes + 15) & ~(size_t)15;
+        return p;
+    };
+    const int MB = MT * 16, S = d.S, A = d.A, LDH = ldh_for(d.H1);
+    float* hbuf = (float*)take(sizeof(float) * MB * LDH);
+    double* r = (double*)take(sizeof(double) * MB);
+    double* g = (double*)take(sizeof(double) * MB);
+    long long* idx = (long long*)take(sizeof(long long) * RLC_MAX_BATCH);
+    unsigned short* mask = (unsigned short*)take(sizeof(unsigned short) * MB * NT16);
+    float* part = (float*)take(sizeof(float) * kWaves * MB * A);
+    float* wvec = (float*)take(sizeof(float) * A * 256);
+    float* x = (float*)take(sizeof(float) * MB * S);
+    float* x2 = (float*)take(sizeof(float) * MB * S);
+    float* a = (float*)take(sizeof(float) * MB * A);
+    float* aout = (float*)take(sizeof(float) * MB * A);
+    float* mu = (float*)take(sizeof(float) * MB * A);
+    float* dz = (float*)take(sizeof(float) * MB * A);
+    float* q = (float*)take(sizeof(float) * MB);
+    float* y = (float*)take(sizeof(float) * MB);
+    float* dq = (float*)take(sizeof(float) * MB);
+    int* pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
+    int* dups = (int*)take(sizeof(int) * 4);
+    if (out) {
+        out->hbuf = hbuf; out->r = r; out->g = g; out->idx = idx; out->mask = mask; out->part = part;
+        out->wvec = wvec; out->x = x; out->x2 = x2; out->a = a; out->aout = aout; out->mu = mu; out->dz = dz;
+        out->q = q; out->y = y; out->dq = dq; out->pool = pool; out->dups = dups;
+    }
+    return off;
+}
+
+template <int MT, int AD>
+struct Upd {
+    static constexpr int MB = MT * 16;
+
+    // per-thread geometry
+    int tid, lane, wave, c, g;
+    int S, H1, HA, HC, B, LDH;
+    Smem L;
+
+    // ---------------------------------------------------------------------------------------
+    // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
+    // ---------------------------------------------------------------------------------------
+    __device__ __forceinline__ void trunk(const float* W1, const float* b1, const float* xs) {
+        // 256 column slots x 2 row halves
+        const int half = tid >> 8;
+        for (int k = tid & 255; k < LDH; k += 256) {
+            float w[SMAX];
+            float bias = 0.0f;
+            const bool live = k < H1;
+#pragma unroll
+            for (int i = 0; i < SMAX; i++) w[i] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
+            if (live) bias = b1[k];
+            for (int b = half * (MB / 2); b < (half + 1) * (MB / 2); b++) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < SMAX; i++)
+                    if (i < S) acc += xs[b * S + i] * w[i];
+                acc = fmaxf(acc + bias, 0.0f);
+                L.hbuf[b * LDH + k] = (live && b < B) ? acc : 0.0f;
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // forward GEMM: acc[mt][i] (tile rows 16mt.., cols 16*(wave+4i)..) = hbuf[:, 0:K] . W[0:K, :]
+    // A: one ds_read_b128 per M tile per 16-deep chunk, lane (c,g) holds k = kc+4g+s for step s;
+    // B: W[(kc+4g+s)*N + col] streamed global -> VGPR, next chunk prefetched under the MFMAs.
+    // ---------------------------------------------------------------------------------------
+    __device__ __forceinline__ void fwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int N, int K) {
+        const int NT = (N + 15) >> 4;
+        int col[NTW];
+        bool own[NTW], cval[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = wave + kWaves * i;
+            own[i] = t < NT;
+            col[i] = 16 * t + c;
+            cval[i] = own[i] && col[i] < N;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        float bcur[NTW][4], bnxt[NTW][4];
+        auto loadB = [&](float (&dst)[NTW][4], int kc) {
+            const int k0 = kc + 4 * g;
+            const bool kval = k0 < K;
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    dst[i][s] = (kval && cval[i]) ? W[(size_t)(k0 + s) * N + col[i]] : 0.0f;
+        };
+        loadB(bcur, 0);
+        for (int kc = 0; kc < K; kc += 16) {
+            loadB(bnxt, kc + 16);      // past-the-end chunks load zeros (predicated off)
+            const bool kval = kc + 4 * g < K;
+            f32x4 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(&L.hbuf[(16 * mt + c) * LDH + kc + 4 * g]);
+                av[mt] = kval ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+                    if (own[i]) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], bcur[i][s], acc[mt][i]);
+                    }
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) bcur[i][s] = bnxt[i][s];
+        }
+    }
+
+    // acc += bias[n] + sum_j E[b][j] * Wx[j][n] ; relu          (E = action rows of the critic concat)
+    __device__ __forceinline__ void bias_relu(f32x4 (&acc)[MT][NTW], const float* bias, int N, const float* E,
+                                              const float* Wx /* [AD][N] or null */) {
+        const int NT = (N + 15) >> 4;
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = wave + kWaves * i;
+            const int n = 16 * t + c;
+            const bool ok = t < NT && n < N;
+            const float bs = ok ? bias[n] : 0.0f;
+            float wx[AD];
+#pragma unroll
+            for (int j = 0; j < AD; j++) wx[j] = (ok && Wx) ? Wx[(size_t)j * N + n] : 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = acc[mt][i][r] + bs;
+                    if (Wx) {
+                        const int b = 16 * mt + 4 * g + r;
+#pragma unroll
+                        for (int j = 0; j < AD; j++) v += E[b * AD + j] * wx[j];
+                    }
+                    acc[mt][i][r] = ok ? fmaxf(v, 0.0f) : 0.0f;
+                }
+        }
+    }
+
+    // out[b][j] partial over this wave's columns: sum_n f(acc[b][n]) * coef_j[n]; f = identity or step
+    template <bool STEP>
+    __device__ __forceinline__ void row_dot(const f32x4 (&acc)[MT][NTW], int N, const float* coef /* [n*cs + j*js] */,
+                                            int cs, int js, const float* coef2 /* optional multiplier [n] */) {
+        const int NT = (N + 15) >> 4;
+        float cf[NTW][AD];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = wave + kWaves * i;
+            const int n = 16 * t + c;
+            const bool ok = t < NT && n < N;
+#pragma unroll
+            for (int j = 0; j < AD; j++) {
+                float v = ok ? coef[(size_t)n * cs + (size_t)j * js] : 0.0f;
+                if (coef2) v *= ok ? coef2[n] : 0.0f;
+                cf[i][j] = v;
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int j = 0; j < AD; j++) {
+                    float p = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < NTW; i++) {
+                        const float v = acc[mt][i][r];
+                        p += STEP ? (v > 0.0f ? cf[i][j] : 0.0f) : v * cf[i][j];
+                    }
+                    p = row16_sum(p);
+                    if (c == 0) L.part[((size_t)wave * MB + 16 * mt + 4 * g + r) * AD + j] = p;
+                }
+    }
+
+    // fixed-order sum of the waves' partials
+    __device__ __forceinline__ float part_sum(int b, int j) const {
+        float s = L.part[((size_t)0 * MB + b) * AD + j];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) s += L.part[((size_t)w * MB + b) * AD + j];
+        return s;
+    }
+
+    // relu masks of the accumulators -> mask16[b][tile]
+    __device__ __forceinline__ void store_masks(const f32x4 (&acc)[MT][NTW], int N) {
+        const int NT = (N + 15) >> 4;
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = wave + kWaves * i;
+            if (t < NT) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const unsigned long long bal = __ballot(acc[mt][i][r] > 0.0f);
+                        if (c == 0) L.mask[(16 * mt + 4 * g + r) * NT16 + t] = (unsigned short)(bal >> (16 * g));
+                    }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // backward-to-input GEMM: acc[b][k'] = sum_n D[b][n] * W[k'][n],  D[b][n] = mask(b,n) * sum_j seed[b][j]*wv[j][n]
+    // (D is never materialised).  k-dim = n in chunks of 16 with lane (c,g) taking n = nc+4g+s:
+    //   A  from mask16 + seed (registers) + wvec (LDS);  B = one dwordx4 of row k' of W per chunk.
+    // ---------------------------------------------------------------------------------------
+    template <int NS>
+    __device__ __forceinline__ void bwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int Nk /* row length = k-dim */,
+                                             int Kout /* rows of W used = H1 */, const float* seed /* LDS [MB][NS] */) {
+        const int NT = (Kout + 15) >> 4;
+        int row[NTW];
+        bool own[NTW], rval[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = wave + kWaves * i;
+            own[i] = t < NT;
+            row[i] = 16 * t + c;
+            rval[i] = own[i] && row[i] < Kout;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float sd[MT][NS];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
+
+        f32x4 bcur[NTW], bnxt[NTW];
+        auto loadB = [&](f32x4 (&dst)[NTW], int nc) {
+            const int n0 = nc + 4 * g;
+            const bool nval = n0 < Nk;
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+                dst[i] = (nval && rval[i]) ? *reinterpret_cast<const f32x4*>(&W[(size_t)row[i] * Nk + n0])
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+        };
+        loadB(bcur, 0);
+        for (int nc = 0; nc < Nk; nc += 16) {
+            loadB(bnxt, nc + 16);      // past-the-end chunks load zeros (predicated off)
+            const int n0 = nc + 4 * g;
+            const bool nval = n0 < Nk;
+            f32x4 wv[NS];
+#pragma unroll
+            for (int j = 0; j < NS; j++)
+                wv[j] = nval ? *reinterpret_cast<const f32x4*>(&L.wvec[j * 256 + n0]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const unsigned m = L.mask[(16 * mt + c) * NT16 + (nc >> 4)];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    float v = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NS; j++) v += sd[mt][j] * wv[j][s];
+                    av[mt][s] = ((m >> (4 * g + s)) & 1u) ? v : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++)
+                    if (own[i]) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], bcur[i][s], acc[mt][i]);
+                    }
+#pragma unroll
+            for (int i = 0; i < NTW; i++) bcur[i] = bnxt[i];
+        }
+    }
+
+    // epilogue of bwd_gemm: dh1 = acc * (hbuf > 0); column-reduce into the W1 / b1 gradients of this wave's
+    // trunk units and apply Adam (+ optional Polyak) right here.
+    __device__ __forceinline__ void trunk_grad_adam(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
+                                                    float alpha, int oW1, int ob1, float* tap, float* tt, float tau) {
+        const int NT = (H1 + 15) >> 4;
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = wave + kWaves * i;
+            if (t >= NT) continue;
+            const int k = 16 * t + c;
+            float gb = 0.0f;
+            float gw[SMAX];
+#pragma unroll
+            for (int s = 0; s < SMAX; s++) gw[s] = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int b = 16 * mt + 4 * g + r;
+                    const float d = (k < H1 && L.hbuf[b * LDH + k] > 0.0f) ? acc[mt][i][r] : 0.0f;
+                    gb += d;
+#pragma unroll
+                    for (int s = 0; s < SMAX; s++)
+                        if (s < S) gw[s] += L.x[b * S + s] * d;
+                }
+            gb = col4_sum(gb);
+#pragma unroll
+            for (int s = 0; s < SMAX; s++)
+                if (s < S) gw[s] = col4_sum(gw[s]);
+            // lanes g == s' handle row s' (spread the Adam work over the 4 lane groups)
+            if (k < H1) {
+                for (int s = g; s <= S; s += 4) {
+                    const bool is_bias = s == S;
+                    float gr = gb;
+#pragma unroll
+                    for (int q = 0; q < SMAX; q++)
+                        if (q == s && !is_bias) gr = gw[q];
+                    const int p = is_bias ? ob1 + k : oW1 + s * H1 + k;
+                    float mm = m[p], vv = v[p];
+                    const float nv = adam_step(th[p], gr, mm, vv, alpha);
+                    m[p] = mm; v[p] = vv; th[p] = nv;
+                    if (tap) tap[p] = gr;
+                    if (tt) { const float o = tt[p]; tt[p] = o + tau * (nv - o); }
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // weight-gradient GEMM + Adam (+Polyak) epilogue:
+    //   G[k'][n] = sum_b X[b][k'] * D[b][n],  X = [hbuf | E] (E = action columns, or none), D as above.
+    // Output rows k' on the MFMA M axis (A operand = hbuf read as columns), cols n owned per wave;
+    // k-dim = batch, lane group g takes b = 16*bt + 4*s + {0,2,1,3}[g] (bank-conflict-free b32 reads).
+    // ---------------------------------------------------------------------------------------
+    template <int NS>
+    __device__ __forceinline__ void wgrad_adam(const float* seed /* LDS [MB][NS] */, const float* E /* LDS [MB][AD] or null */,
+                                               int Krows /* H1 (+AD if E) */, int N, float* Wp, float* mp, float* vp,
+                                               float alpha, float* tapp, float* Wt, float tau) {
+        const int NT = (N + 15) >> 4;
+        const int NMT = (Krows + 15) >> 4;
+        const int gperm = ((g & 1) << 1) | (g >> 1);     // 0,2,1,3
+        for (int i = 0; i < NTW; i++) {
+            const int t = wave + kWaves * i;
+            if (t >= NT) break;
+            const int n = 16 * t + c;
+            const bool nok = n < N;
+            float wvn[NS];
+#pragma unroll
+            for (int j = 0; j < NS; j++) wvn[j] = nok ? L.wvec[j * 256 + n] : 0.0f;
+            for (int m0 = 0; m0 < NMT; m0 += MC) {
+                f32x4 acc[MC];
+#pragma unroll
+                for (int q = 0; q < MC; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ks = 0; ks < MT * 4; ks++) {
+                    const int b = 4 * ks + gperm;
+                    // B fragment: D[b][n]
+                    float dv = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
+                    const unsigned mword = L.mask[b * NT16 + t];
+                    const float bf = ((mword >> c) & 1u) ? dv : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < MC; q++) {
+                        const int mt = m0 + q;
+                        if (mt < NMT) {
+                            const int kp = 16 * mt + c;
+                            float af;
+                            if (kp < H1) af = L.hbuf[b * LDH + kp];
+                            else if (E != nullptr && kp < Krows) af = E[b * AD + (kp - H1)];
+                            else af = 0.0f;
+                            acc[q] = mfma16(af, bf, acc[q]);
+                        }
+                    }
+                }
+                // epilogue: element r of acc[q] is G[16*(m0+q) + 4g + r][n]
+#pragma unroll
+                for (int q = 0; q < MC; q++) {
+                    const int mt = m0 + q;
+                    __builtin_amdgcn_sched_barrier(0);     // keep one tile's loads/stores live at a time
+                    if (mt < NMT) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int kp = 16 * mt + 4 * g + r;
+                            if (kp < Krows && nok) {
+                                const size_t p = (size_t)kp * N + n;
+                                float mm = mp[p], vv = vp[p];
+                                const float gr = acc[q][r];
+                                const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
+                                mp[p] = mm; vp[p] = vv; Wp[p] = nv;
+                                if (tapp) tapp[p] = gr;
+                                const float o = Wt[p];
+                                Wt[p] = o + tau * (nv - o);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+};
+
+template <int MT, int AD>
+__global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev dv, int first_agent, int n_updates,
+                                                                        int source, const long long* host_idx,
+                                                                        int grad_taps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using U = Upd<MT, AD>;
+    constexpr int MB = U::MB;
+    const RlcDims d = dv.d;
+    U u;
+    u.tid = threadIdx.x; u.lane = u.tid & 63; u.wave = __builtin_amdgcn_readfirstlane(u.tid >> 6);
+    u.c = u.lane & 15; u.g = u.lane >> 4;
+    u.S = d.S; u.H1 = d.H1; u.HA = d.HA; u.HC = d.HC; u.B = d.B; u.LDH = ldh_for(d.H1);
+    smem_carve(d, MT, smem, &u.L);
+    Smem& L = u.L;
+    const int tid = u.tid, S = d.S, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
+    const int agent = first_agent + blockIdx.x;
+
+    float* th = dv.theta + (size_t)agent * d.Ppad;
+    float* tt = dv.theta_t + (size_t)agent * d.Ppad;
+    float* m_a = dv.m_a + (size_t)agent * d.Ppad;
+    float* v_a = dv.v_a + (size_t)agent * d.Ppad;
+    float* m_c = dv.m_c + (size_t)agent * d.Ppad;
+    float* v_c = dv.v_c + (size_t)agent * d.Ppad;
+    float* pw = dv.pw + agent * 4;
+    const float lr_a = dv.actor_lr[agent], lr_c = dv.critic_lr[agent], tau = dv.tau;
+    float* tap_gc = grad_taps ? dv.tap_gc + (size_t)agent * d.Ppad : nullptr;
+    float* tap_ga = grad_taps ? dv.tap_ga + (size_t)agent * d.Ppad : nullptr;
+    float amax[AD];
+#pragma unroll
+    for (int j = 0; j < AD; j++) amax[j] = dv.amax[j];
+
+    // zero the padded tails of the per-sample vectors once (rows >= B never change afterwards)
+    for (int i = tid; i < MB * AD; i += kThreads) { L.a[i] = 0.f; L.aout[i] = 0.f; L.mu[i] = 0.f; L.dz[i] = 0.f; }
+    for (int i = tid; i < MB * S; i += kThreads) { L.x[i] = 0.f; L.x2[i] = 0.f; }
+    for (int i = tid; i < MB; i += kThreads) { L.q[i] = 0.f; L.y[i] = 0.f; L.dq[i] = 0.f; }
+    for (int i = tid; i < MB * NT16; i += kThreads) L.mask[i] = 0;
+    __syncthreads();
+
+    f32x4 acc[MT][NTW];
+
+    for (int upd = 0; upd < n_updates; upd++) {
+        // Re-materialise lane geometry every update: without this hipcc hoists the address arithmetic of
+        // all ~15 phases out of the update loop and then spills it (190 scratch stores in the prologue).
+        asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));
+        // ================= sample + gather (utils/replaybuffer.py:32-37) =================
+        const RlcRingMeta ring = dv.ring[agent];
+        if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
+            const unsigned long long call = dv.sample_ctr[agent];
+            __syncthreads();
+            rlc_sample_distinct(ring.size, B, dv.seed[agent], call, L.pool, L.idx, L.dups);
+            if (tid == 0) dv.sample_ctr[agent] = call + 1;
+        } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
+            for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + upd) * B + b];
+        }
+        __syncthreads();
+        for (int b = tid; b < B; b += kThreads) {
+            const float *ps, *pa, *ps2;
+            if (source == RLC_SRC_STAGING) {
+                const size_t slot = (size_t)agent * RLC_MAX_BATCH + b;
+                ps = dv.gs + slot * S; pa = dv.ga + slot * AD; ps2 = dv.gs2 + slot * S;
+                L.r[b] = dv.gr[slot]; L.g[b] = dv.gg[slot];
+            } else {
+                const size_t slot = (size_t)agent * dv.cap + ring_slot(ring, dv.cap, L.idx[b]);
+                ps = dv.rs + slot * S; pa = dv.ra + slot * AD; ps2 = dv.rs2 + slot * S;
+                L.r[b] = dv.rr[slot]; L.g[b] = dv.rg[slot];
+            }
+            for (int i = 0; i < S; i++) {
+                L.x[b * S + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x2[b * S + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
+        }
+        __syncthreads();
+
+        // ================= steps 1-2: target networks on s' (DDPG.py:77) =================
+        u.trunk(tt + d.oW1, tt + d.ob1, L.x2);
+        __syncthreads();
+        u.fwd_gemm(acc, tt + d.oWa2, HA, H1);
+        u.bias_relu(acc, tt + d.oba2, HA, nullptr, nullptr);
+        u.template row_dot<false>(acc, HA, tt + d.oWa3, AD, 1, nullptr);          // z' partials
+        __syncthreads();
+        for (int i = tid; i < B * AD; i += kThreads) {
+            const int b = i / AD, j = i % AD;
+            L.aout[i] = tanhf(u.part_sum(b, j) + tt[d.oba3 + j]) * amax[j];
+        }
+        __syncthreads();
+        u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
+        u.bias_relu(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2 + (size_t)H1 * HC);
+        // q' partials: only column j = 0 of the partial buffer is meaningful here
+        {
+            // reuse row_dot with coef = Wc3' (stride 1, js 0 -> every j gets the same value)
+            u.template row_dot<false>(acc, HC, tt + d.oWc3, 1, 0, nullptr);
+        }
+        __syncthreads();
+        for (int b = tid; b < B; b += kThreads) {
+            const float qt = u.part_sum(b, 0) + tt[d.obc3];
+            const float y = (float)(L.r[b] + L.g[b] * (double)qt);     // float64 TD glue (DDPG.py:80-84)
+            L.y[b] = y;
+            dv.tap_y[(size_t)agent * RLC_MAX_BATCH + b] = y;
+        }
+        __syncthreads();
+
+        // ================= step 3: critic step =================
+        u.trunk(th + d.oW1, th + d.ob1, L.x);
+        for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < HC ? th[d.oWc3 + n] : 0.0f;
+        __syncthreads();
+        u.fwd_gemm(acc, th + d.oWc2, HC, H1);
+        u.bias_relu(acc, th + d.obc2, HC, L.a, th + d.oWc2 + (size_t)H1 * HC);
+        u.template row_dot<false>(acc, HC, th + d.oWc3, 1, 0, nullptr);           // q partials
+        __syncthreads();
+        for (int b = tid; b < B; b += kThreads) {
+            const float q = u.part_sum(b, 0) + th[d.obc3];
+            L.q[b] = q;
+            dv.tap_q[(size_t)agent * RLC_MAX_BATCH + b] = q;
+            L.dq[b] = 2.0f * (q - L.y[b]) / (float)B;                  // d mean((y-q)^2)/dq
+        }
+        __syncthreads();
+        // wave-local column reductions from the live g2 accumulators: dWc3, dbc2; then the relu masks
+        float g_wc3[NTW], g_bc2[NTW];
+        {
+            const int NT = (HC + 15) >> 4;
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                const int t = u.wave + kWaves * i;
+                const int n = 16 * t + u.c;
+                const float w3 = (t < NT && n < HC) ? L.wvec[n] : 0.0f;
+                float s3 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const f32x4 dq4 = *reinterpret_cast<const f32x4*>(&L.dq[16 * mt + 4 * u.g]);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float gv = acc[mt][i][r];
+                        s3 += gv * dq4[r];
+                        s2 += gv > 0.0f ? dq4[r] * w3 : 0.0f;
+                    }
+                }
+                g_wc3[i] = col4_sum(s3);
+                g_bc2[i] = col4_sum(s2);
+            }
+        }
+        u.store_masks(acc, HC);
+        __syncthreads();
+        // dh1 = (dg2 . Wc2[:H1]^T) * relu'(h1) -> W1/b1 gradients -> critic Adam on the trunk (Q1)
+        const float alpha_c = adam_alpha(lr_c, pw[2], pw[3]);
+        u.template bwd_gemm<1>(acc, th + d.oWc2, HC, H1, L.dq);
+        __syncthreads();      // every wave has finished reading the pre-step Wc2 rows and W1
+#ifndef RLC_EXP_NOTRUNKG
+        u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f);
+#endif
+        // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue
+#ifndef RLC_EXP_NOWGRAD
+        u.template wgrad_adam<1>(L.dq, L.a, H1 + AD, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
+                     tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau);
+#endif
+        // small critic tensors: Wc3, bc2 (column owners), bc3 (one thread)
+        {
+            const int NT = (HC + 15) >> 4;
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                const int t = u.wave + kWaves * i;
+                const int n = 16 * t + u.c;
+                if (t < NT && n < HC && u.g < 2) {
+                    const int p = (u.g == 0) ? d.oWc3 + n : d.obc2 + n;
+                    const float gr = (u.g == 0) ? g_wc3[i] : g_bc2[i];
+                    float mm = m_c[p], vv = v_c[p];
+                    const float nv = adam_step(th[p], gr, mm, vv, alpha_c);
+                    m_c[p] = mm; v_c[p] = vv; th[p] = nv;
+                    if (tap_gc) tap_gc[p] = gr;
+                    const float o = tt[p];
+                    tt[p] = o + tau * (nv - o);
+                }
+            }
+            if (tid == 0) {
+                float gr = 0.0f;
+                for (int b = 0; b < B; b++) gr += L.dq[b];
+                const int p = d.obc3;
+                float mm = m_c[p], vv = v_c[p];
+                const float nv = adam_step(th[p], gr, mm, vv, alpha_c);
+                m_c[p] = mm; v_c[p] = vv; th[p] = nv;
+                if (tap_gc) tap_gc[p] = gr;
+                const float o = tt[p];
+                tt[p] = o + tau * (nv - o);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
+
+        // ================= step 4: actor forward with the updated trunk (DDPG.py:90) =================
+        u.trunk(th + d.oW1, th + d.ob1, L.x);
+        for (int i = tid; i < AD * 256; i += kThreads) {
+            const int j = i / 256, n = i % 256;
+            L.wvec[i] = n < HA ? th[d.oWa3 + n * AD + j] : 0.0f;       // Wa3 transposed [j][n]
+        }
+        __syncthreads();
+        u.fwd_gemm(acc, th + d.oWa2, HA, H1);
+        u.bias_relu(acc, th + d.oba2, HA, nullptr, nullptr);
+        u.template row_dot<false>(acc, HA, th + d.oWa3, AD, 1, nullptr);          // z partials
+        u.store_masks(acc, HA);
+        __syncthreads();
+        for (int i = tid; i < B * AD; i += kThreads) {
+            const int b = i / AD, j = i % AD;
+            const float mu = tanhf(u.part_sum(b, j) + th[d.oba3 + j]);
+            L.mu[i] = mu;
+            const float ao = mu * amax[j];
+            L.aout[i] = ao;
+            dv.tap_aout[(size_t)agent * RLC_MAX_BATCH * AD + i] = ao;
+        }
+        __syncthreads();
+        // the h2 accumulators are needed again for dWa3 once dz is known: park them in registers
+        f32x4 h2acc[MT][NTW];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) h2acc[mt][i] = acc[mt][i];
+#ifdef RLC_EXP_NOPARK
+#define h2acc acc
+#endif
+
+        // ================= step 5: dQ/da at the scaled action, updated critic (DDPG.py:91) =================
+        u.fwd_gemm(acc, th + d.oWc2, HC, H1);
+        u.bias_relu(acc, th + d.obc2, HC, L.aout, th + d.oWc2 + (size_t)H1 * HC);
+        // dqda[b][j] = sum_n step(g2[b][n]) * Wc3[n] * Wc2[H1+j][n]
+        u.template row_dot<true>(acc, HC, th + d.oWc2 + (size_t)H1 * HC, 1, HC, th + d.oWc3);
+        __syncthreads();
+        for (int i = tid; i < B * AD; i += kThreads) {
+            const int b = i / AD, j = i % AD;
+            const float dqda = u.part_sum(b, j);
+            dv.tap_dqda[(size_t)agent * RLC_MAX_BATCH * AD + i] = dqda;
+            const float mu = L.mu[i];
+            L.dz[i] = -dqda * (1.0f - mu * mu);                         // grad_ys = -dQ/da on tanh output (Q3)
+        }
+        __syncthreads();
+
+        // ================= step 6: actor step =================
+        float g_wa3[NTW][AD], g_ba2[NTW];
+        {
+            const int NT = (HA + 15) >> 4;
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                const int t = u.wave + kWaves * i;
+                const int n = 16 * t + u.c;
+                const bool ok = t < NT && n < HA;
+                float w3[AD], s3[AD];
+#pragma unroll
+                for (int j = 0; j < AD; j++) { w3[j] = ok ? L.wvec[j * 256 + n] : 0.0f; s3[j] = 0.0f; }
+                float s2 = 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int b = 16 * mt + 4 * u.g + r;
+                        const float hv = h2acc[mt][i][r];
+                        float dd = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < AD; j++) {
+                            const float dzb = L.dz[b * AD + j];
+                            s3[j] += hv * dzb;
+                            dd += dzb * w3[j];
+                        }
+                        s2 += hv > 0.0f ? dd : 0.0f;
+                    }
+#pragma unroll
+                for (int j = 0; j < AD; j++) g_wa3[i][j] = col4_sum(s3[j]);
+                g_ba2[i] = col4_sum(s2);
+            }
+        }
+        const float alpha_a = adam_alpha(lr_a, pw[0], pw[1]);
+        u.template bwd_gemm<AD>(acc, th + d.oWa2, HA, H1, L.dz);
+        __syncthreads();
+#ifndef RLC_EXP_NOTRUNKG
+        u.trunk_grad_adam(acc, th, m_a, v_a, alpha_a, d.oW1, d.ob1, tap_ga, tt, tau);
+#endif
+#ifndef RLC_EXP_NOWGRAD
+        u.template wgrad_adam<AD>(L.dz, nullptr, H1, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
+                     tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau);
+#endif
+        {
+            const int NT = (HA + 15) >> 4;
+#pragma unroll
+            for (int i = 0; i < NTW; i++) {
+                const int t = u.wave + kWaves * i;
+                const int n = 16 * t + u.c;
+                if (t < NT && n < HA && u.g <= AD) {
+                    // lane group 0 -> ba2[n]; groups 1..AD -> Wa3[n][j]
+                    int p = d.oba2 + n;
+                    float gr = g_ba2[i];
+#pragma unroll
+                    for (int j = 0; j < AD; j++)
+                        if (u.g == j + 1) { p = d.oWa3 + n * AD + j; gr = g_wa3[i][j]; }
+                    float mm = m_a[p], vv = v_a[p];
+                    const float nv = adam_step(th[p], gr, mm, vv, alpha_a);
+                    m_a[p] = mm; v_a[p] = vv; th[p] = nv;
+                    if (tap_ga) tap_ga[p] = gr;
+                    const float o = tt[p];
+                    tt[p] = o + tau * (nv - o);
+                }
+            }
+            if (tid < AD) {
+                float gr = 0.0f;
+                for (int b = 0; b < B; b++) gr += L.dz[b * AD + tid];
+                const int p = d.oba3 + tid;
+                float mm = m_a[p], vv = v_a[p];
+                const float nv = adam_step(th[p], gr, mm, vv, alpha_a);
+                m_a[p] = mm; v_a[p] = vv; th[p] = nv;
+                if (tap_ga) tap_ga[p] = gr;
+                const float o = tt[p];
+                tt[p] = o + tau * (nv - o);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
+        __syncthreads();
+    }
+}
+
+template <int MT, int AD>
+int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
+             int grad_taps, hipStream_t st) {
+    const size_t lds = smem_carve(dv.d, MT, nullptr, nullptr);
+    RLC_REQUIRE(lds <= 160 * 1024, "MFMA DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
+    auto kern = rlc_ddpg_update_mfma_kernel<MT, AD>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates, source, idx_dev,
+                       grad_taps);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace

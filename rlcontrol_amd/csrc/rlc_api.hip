@@ -251,9 +251,22 @@ int rlc_ddpg_set_blob(rlc_ddpg* h, int32_t agent, int32_t which, const float* sr
     if (check_agent(h, agent) || use_device(h)) return 2;
     float* base = blob_ptr(h, which);
     RLC_REQUIRE(base && src, "bad blob selector %d or null src", which);
-    RLC_REQUIRE(n == h->dv.d.P, "blob length %lld != parameter count %d", (long long)n, h->dv.d.P);
-    RLC_HIP(hipMemcpyAsync(base + (size_t)agent * h->dv.d.Ppad, src, n * sizeof(float), hipMemcpyHostToDevice, h->st));
+    const RlcDims& d = h->dv.d;
+    RLC_REQUIRE(n == d.P, "blob length %lld != parameter count %d", (long long)n, d.P);
+    std::vector<float> padded(d.Ppad, 0.0f);     // compact ABI blob -> padded device layout
+    for (int i = 0; i < 10; i++) memcpy(&padded[d.seg_dev[i]], src + d.seg_compact[i], sizeof(float) * d.seg_len[i]);
+    RLC_HIP(hipMemcpyAsync(base + (size_t)agent * d.Ppad, padded.data(), sizeof(float) * d.Ppad,
+                           hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+static int fetch_blob(rlc_ddpg* h, const float* dev_src, float* dst) {
+    const RlcDims& d = h->dv.d;
+    std::vector<float> padded(d.Ppad);
+    RLC_HIP(hipMemcpyAsync(padded.data(), dev_src, sizeof(float) * d.Ppad, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    for (int i = 0; i < 10; i++) memcpy(dst + d.seg_compact[i], &padded[d.seg_dev[i]], sizeof(float) * d.seg_len[i]);
     return 0;
 }
 
@@ -262,9 +275,7 @@ int rlc_ddpg_get_blob(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int
     float* base = blob_ptr(h, which);
     RLC_REQUIRE(base && dst, "bad blob selector %d or null dst", which);
     RLC_REQUIRE(n == h->dv.d.P, "blob length %lld != parameter count %d", (long long)n, h->dv.d.P);
-    RLC_HIP(hipMemcpyAsync(dst, base + (size_t)agent * h->dv.d.Ppad, n * sizeof(float), hipMemcpyDeviceToHost, h->st));
-    RLC_HIP(hipStreamSynchronize(h->st));
-    return 0;
+    return fetch_blob(h, base + (size_t)agent * h->dv.d.Ppad, dst);
 }
 
 int rlc_ddpg_set_beta_powers(rlc_ddpg* h, int32_t agent, const float* pw4) {
@@ -286,7 +297,7 @@ int rlc_ddpg_get_beta_powers(rlc_ddpg* h, int32_t agent, float* pw4) {
 int rlc_ddpg_init_target(rlc_ddpg* h, int32_t agent) {
     if (check_agent(h, agent) || use_device(h)) return 2;
     const size_t off = (size_t)agent * h->dv.d.Ppad;
-    RLC_HIP(hipMemcpyAsync(h->dv.theta_t + off, h->dv.theta + off, h->dv.d.P * sizeof(float),
+    RLC_HIP(hipMemcpyAsync(h->dv.theta_t + off, h->dv.theta + off, h->dv.d.Ppad * sizeof(float),
                            hipMemcpyDeviceToDevice, h->st));
     return 0;
 }
@@ -582,6 +593,7 @@ int rlc_ddpg_last_tap(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int
     }
     RLC_REQUIRE(src, "tap %d not available (gradient taps need rlc_ddpg_enable_grad_taps)", which);
     RLC_REQUIRE(n == want, "tap %d holds %lld floats, caller asked for %lld", which, want, (long long)n);
+    if (which >= 4) return fetch_blob(h, src, dst);     // gradient blobs use the padded device layout
     RLC_HIP(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;

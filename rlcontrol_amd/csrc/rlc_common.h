@@ -38,27 +38,34 @@ void rlc_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------------------------
 struct RlcDims {
     int S, A, H1, HA, HC, B;
+    // DEVICE offsets of the ten tensors inside one agent's blob: each tensor starts on a 256-byte
+    // boundary so that rows can be fetched with 16-byte vector loads.  The ABI's compact blob
+    // (rlc_ddpg_set_blob / get_blob) is packed/unpacked on the host with seg_* below.
     int oW1, ob1, oWa2, oba2, oWa3, oba3, oWc2, obc2, oWc3, obc3;
-    int P;      // parameter count
-    int Ppad;   // per-agent stride of every blob (P rounded up to 64 floats = 256 B)
+    int P;      // parameter count of the compact ABI blob
+    int Pdev;   // extent of the padded device layout
+    int Ppad;   // per-agent stride of every device blob (= Pdev, multiple of 64 floats)
+    int seg_len[10], seg_compact[10], seg_dev[10];
 };
 
 inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B) {
     RlcDims d;
     d.S = S; d.A = A; d.H1 = H1; d.HA = HA; d.HC = HC; d.B = B;
-    int p = 0;
-    d.oW1 = p;  p += S * H1;
-    d.ob1 = p;  p += H1;
-    d.oWa2 = p; p += H1 * HA;
-    d.oba2 = p; p += HA;
-    d.oWa3 = p; p += HA * A;
-    d.oba3 = p; p += A;
-    d.oWc2 = p; p += (H1 + A) * HC;
-    d.obc2 = p; p += HC;
-    d.oWc3 = p; p += HC;
-    d.obc3 = p; p += 1;
-    d.P = p;
-    d.Ppad = (p + 63) & ~63;
+    const int len[10] = {S * H1, H1, H1 * HA, HA, HA * A, A, (H1 + A) * HC, HC, HC, 1};
+    int pc = 0, pd = 0;
+    for (int i = 0; i < 10; i++) {
+        d.seg_len[i] = len[i];
+        d.seg_compact[i] = pc;
+        d.seg_dev[i] = pd;
+        pc += len[i];
+        pd += (len[i] + 63) & ~63;
+    }
+    d.oW1 = d.seg_dev[0]; d.ob1 = d.seg_dev[1]; d.oWa2 = d.seg_dev[2]; d.oba2 = d.seg_dev[3];
+    d.oWa3 = d.seg_dev[4]; d.oba3 = d.seg_dev[5]; d.oWc2 = d.seg_dev[6]; d.obc2 = d.seg_dev[7];
+    d.oWc3 = d.seg_dev[8]; d.obc3 = d.seg_dev[9];
+    d.P = pc;
+    d.Pdev = pd;
+    d.Ppad = pd;
     return d;
 }
 

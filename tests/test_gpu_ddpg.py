@@ -60,13 +60,14 @@ CASES = [((3, 1, 200, 200, 200), 100), ((3, 1, 200, 200, 200), 32), ((8, 2, 200,
 
 
 def _skip_unless_supported(pop, kernel):
-    if kernel == "mfma":
-        from rlcontrol_amd._lib import RlcError
-        try:
-            pop.set_kernel("mfma")
-        except RlcError:
-            pop.close()
-            pytest.skip("MFMA kernel does not cover these dimensions (generic kernel does)")
+    """select the kernel under test explicitly ('auto' would pick mfma wherever it is supported)"""
+    from rlcontrol_amd._lib import RlcError
+    try:
+        pop.set_kernel(kernel)
+    except RlcError:
+        pop.close()
+        pytest.skip("MFMA kernel does not cover these dimensions (generic kernel does)")
+    assert pop.kernel_in_use() == kernel
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
