@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librlcontrol_hip.so")
+LIB_PATH = os.environ.get("RLCONTROL_HIP_LIB", os.path.join(_HERE, "librlcontrol_hip.so"))
 
 # every symbol include/rlcontrol_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (

@@ -10,11 +10,18 @@ from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-OUT = os.path.join(_HERE, "librlcontrol_hip.so")
+# RLC_STAMPS=1: diagnostic build with in-kernel phase stamps (never the shipped library)
+STAMPS = os.environ.get("RLC_STAMPS", "0") == "1"
+OBJ = os.path.join(CSRC, ("_obj_stamps" if STAMPS else "_obj") + ("_fast" if os.environ.get("RLC_FAST_BUILD", "0") == "1" else ""))
+OUT = os.path.join(_HERE, "librlcontrol_hip_stamps.so" if STAMPS else "librlcontrol_hip.so")
 PLAIN = ("rlc_api.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip")
 MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+FAST = os.environ.get("RLC_FAST_BUILD", "0") == "1"     # developer loop: only the headline shape
+if FAST:
+    MFMA_VARIANTS = [(7, 1)]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DRLC_STAMPS"] if STAMPS else [])
+if os.environ.get("RLC_FAST_BUILD", "0") == "1":
+    CFLAGS.append("-DRLC_ONLY_7_1")
 
 
 def _hipcc():
@@ -39,8 +46,17 @@ def _stale(src, obj, hdr_time):
     return (not os.path.exists(obj)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
 
 
+VARIANT_TAG = OUT + ".variant"
+VARIANT = "fast" if FAST else "full"
+
+
 def needs_build():
     if not os.path.exists(OUT):
+        return True
+    try:
+        if open(VARIANT_TAG).read().strip() != VARIANT:
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(OUT)
     srcs = [u[0] for u in _units()] + _headers()
@@ -68,6 +84,8 @@ def build(force=False, verbose=False, jobs=None):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(VARIANT_TAG, "w") as f:
+        f.write(VARIANT)
     return OUT
 
 

@@ -4,8 +4,12 @@
 
 #define RLC_DECL(M, A_)                                                                                   \
     int rlc_mfma_launch_##M##_##A_(const RlcDev&, int, int, int, int, const long long*, int, hipStream_t);
+#ifdef RLC_ONLY_7_1   // developer loop (RLC_FAST_BUILD=1): only the headline shape is compiled
+RLC_DECL(7, 1)
+#else
 RLC_DECL(2, 1) RLC_DECL(4, 1) RLC_DECL(7, 1) RLC_DECL(8, 1)
 RLC_DECL(2, 2) RLC_DECL(4, 2) RLC_DECL(7, 2) RLC_DECL(8, 2)
+#endif
 #undef RLC_DECL
 
 static inline int mt_for(int B) { return B <= 32 ? 2 : (B <= 64 ? 4 : (B <= 112 ? 7 : 8)); }
@@ -26,8 +30,12 @@ int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents,
 #define RLC_CASE(M, A_)                                                                        \
     if (mt == M && dv.d.A == A_)                                                               \
         return rlc_mfma_launch_##M##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st);
+#ifdef RLC_ONLY_7_1
+    RLC_CASE(7, 1)
+#else
     RLC_CASE(2, 1) RLC_CASE(4, 1) RLC_CASE(7, 1) RLC_CASE(8, 1)
     RLC_CASE(2, 2) RLC_CASE(4, 2) RLC_CASE(7, 2) RLC_CASE(8, 2)
+#endif
 #undef RLC_CASE
     rlc_set_error("no MFMA instantiation for MT=%d A=%d", mt, dv.d.A);
     return 3;

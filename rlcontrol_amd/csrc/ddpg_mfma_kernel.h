@@ -94,8 +94,8 @@ __host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, unsigned 
     unsigned short* mask = (unsigned short*)take(sizeof(unsigned short) * MB * NT16);
     float* part = (float*)take(sizeof(float) * kWaves * MB * A);
     float* wvec = (float*)take(sizeof(float) * A * 256);
-    float* x = (float*)take(sizeof(float) * MB * S);
-    float* x2 = (float*)take(sizeof(float) * MB * S);
+    float* x = (float*)take(sizeof(float) * MB * SMAX);      // rows padded to 8 floats: two ds_read_b128
+    float* x2 = (float*)take(sizeof(float) * MB * SMAX);
     float* a = (float*)take(sizeof(float) * MB * A);
     float* aout = (float*)take(sizeof(float) * MB * A);
     float* mu = (float*)take(sizeof(float) * MB * A);
@@ -121,6 +121,17 @@ struct Upd {
     int tid, lane, wave, c, g;
     int S, H1, HA, HC, B, LDH;
     Smem L;
+#ifdef RLC_STAMPS
+    float* stamp_buf = nullptr;
+    long long t_sub = 0;
+    __device__ __forceinline__ void sub_begin() { if (tid == 0) t_sub = clock64(); }
+    __device__ __forceinline__ void sub_stamp(int i) {
+        if (tid == 0 && stamp_buf) { const long long t = clock64(); stamp_buf[i] += (float)(t - t_sub); t_sub = t; }
+    }
+#else
+    __device__ __forceinline__ void sub_begin() {}
+    __device__ __forceinline__ void sub_stamp(int) {}
+#endif
 
     // ---------------------------------------------------------------------------------------
     // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
@@ -135,11 +146,15 @@ struct Upd {
 #pragma unroll
             for (int i = 0; i < SMAX; i++) w[i] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
             if (live) bias = b1[k];
+#pragma unroll 4
             for (int b = half * (MB / 2); b < (half + 1) * (MB / 2); b++) {
-                float acc = 0.0f;
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(&xs[b * SMAX]);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(&xs[b * SMAX + 4]);
+                float acc = 0.0f;      // same i-order as the scalar form; padded lanes multiply by w = 0
 #pragma unroll
-                for (int i = 0; i < SMAX; i++)
-                    if (i < S) acc += xs[b * S + i] * w[i];
+                for (int i = 0; i < 4; i++) acc += x0[i] * w[i];
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc += x1[i] * w[4 + i];
                 acc = fmaxf(acc + bias, 0.0f);
                 L.hbuf[b * LDH + k] = (live && b < B) ? acc : 0.0f;
             }
@@ -381,16 +396,17 @@ struct Upd {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int b = 16 * mt + 4 * g + r;
-                    const float d = (k < H1 && L.hbuf[b * LDH + k] > 0.0f) ? acc[mt][i][r] : 0.0f;
+                    const float hv = L.hbuf[b * LDH + (k < H1 ? k : 0)];
+                    const float d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] : 0.0f;
                     gb += d;
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&L.x[b * SMAX]);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&L.x[b * SMAX + 4]);
 #pragma unroll
-                    for (int s = 0; s < SMAX; s++)
-                        if (s < S) gw[s] += L.x[b * S + s] * d;
+                    for (int s = 0; s < 4; s++) { gw[s] += x0[s] * d; gw[4 + s] += x1[s] * d; }
                 }
             gb = col4_sum(gb);
 #pragma unroll
-            for (int s = 0; s < SMAX; s++)
-                if (s < S) gw[s] = col4_sum(gw[s]);
+            for (int s = 0; s < SMAX; s++) gw[s] = col4_sum(gw[s]);
             // lanes g == s' handle row s' (spread the Adam work over the 4 lane groups)
             if (k < H1) {
                 for (int s = g; s <= S; s += 4) {
@@ -421,7 +437,7 @@ struct Upd {
                                                int Krows /* H1 (+AD if E) */, int N, float* Wp, float* mp, float* vp,
                                                float alpha, float* tapp, float* Wt, float tau) {
         const int NT = (N + 15) >> 4;
-        const int NMT = (Krows + 15) >> 4;
+        const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the trunk units; action rows below
         const int gperm = ((g & 1) << 1) | (g >> 1);     // 0,2,1,3
         for (int i = 0; i < NTW; i++) {
             const int t = wave + kWaves * i;
@@ -432,53 +448,101 @@ struct Upd {
 #pragma unroll
             for (int j = 0; j < NS; j++) wvn[j] = nok ? L.wvec[j * 256 + n] : 0.0f;
             for (int m0 = 0; m0 < NMT; m0 += MC) {
+                // TRANSPOSED tile: acc[q][r] = G[k' = 16(m0+q) + c][n = 16t + 4g + r], i.e. D^T on the A side and
+                // hbuf on the B side, so that each lane owns 4 CONSECUTIVE n of one weight row: the
+                // W / m / v / W' traffic of the Adam epilogue is one 16-byte load + one 16-byte store per array.
                 f32x4 acc[MC];
+                // Prefetch this chunk's W / m / v / W' NOW: their HBM latency hides under the k-loop's MFMAs
+                // instead of serialising in the epilogue (addresses clamped, stores predicated).
+                f32x4 pw_[MC], pm_[MC], pv_[MC], pt_[MC];
+                const int n4 = 16 * t + 4 * g;
+                const bool n4ok = n4 < N;                 // N % 4 == 0: all four columns valid or none
+                sub_begin();
 #pragma unroll
-                for (int q = 0; q < MC; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < MC; q++) {
+                    acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int kp = 16 * (m0 + q) + c;
+                    const size_t p = (kp < H1 && n4ok) ? (size_t)kp * N + n4 : 0;
+                    pw_[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
+                    pm_[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
+                    pv_[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
+                    pt_[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
+                }
+                sub_stamp(21);
+#pragma unroll 4
                 for (int ks = 0; ks < MT * 4; ks++) {
                     const int b = 4 * ks + gperm;
-                    // B fragment: D[b][n]
+                    // D[b][n] for this lane's (b, n = 16t + c)
                     float dv = 0.0f;
 #pragma unroll
                     for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
                     const unsigned mword = L.mask[b * NT16 + t];
-                    const float bf = ((mword >> c) & 1u) ? dv : 0.0f;
+                    const float df = ((mword >> c) & 1u) ? dv : 0.0f;
+                    // hbuf fragments: branch-free (clamped address + select) so the LDS reads issue together
+                    float hf[MC];
 #pragma unroll
                     for (int q = 0; q < MC; q++) {
-                        const int mt = m0 + q;
-                        if (mt < NMT) {
-                            const int kp = 16 * mt + c;
-                            float af;
-                            if (kp < H1) af = L.hbuf[b * LDH + kp];
-                            else if (E != nullptr && kp < Krows) af = E[b * AD + (kp - H1)];
-                            else af = 0.0f;
-                            acc[q] = mfma16(af, bf, acc[q]);
-                        }
+                        const int kp = 16 * (m0 + q) + c;
+                        const float hv = L.hbuf[b * LDH + (kp < H1 ? kp : 0)];
+                        hf[q] = kp < H1 ? hv : 0.0f;
                     }
+#pragma unroll
+                    for (int q = 0; q < MC; q++) acc[q] = mfma16(df, hf[q], acc[q]);
                 }
-                // epilogue: element r of acc[q] is G[16*(m0+q) + 4g + r][n]
+                sub_stamp(22);
 #pragma unroll
                 for (int q = 0; q < MC; q++) {
-                    const int mt = m0 + q;
-                    __builtin_amdgcn_sched_barrier(0);     // keep one tile's loads/stores live at a time
-                    if (mt < NMT) {
+                    const int kp = 16 * (m0 + q) + c;
+                    f32x4 nw, nm = pm_[q], nv = pv_[q], nt;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int kp = 16 * mt + 4 * g + r;
-                            if (kp < Krows && nok) {
-                                const size_t p = (size_t)kp * N + n;
-                                float mm = mp[p], vv = vp[p];
-                                const float gr = acc[q][r];
-                                const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
-                                mp[p] = mm; vp[p] = vv; Wp[p] = nv;
-                                if (tapp) tapp[p] = gr;
-                                const float o = Wt[p];
-                                Wt[p] = o + tau * (nv - o);
-                            }
-                        }
+                    for (int r = 0; r < 4; r++) {
+                        float mm = nm[r], vv = nv[r];
+                        nw[r] = adam_step_fast(pw_[q][r], acc[q][r], mm, vv, alpha);
+                        nm[r] = mm; nv[r] = vv;
+                        nt[r] = pt_[q][r] + tau * (nw[r] - pt_[q][r]);
+                    }
+                    if (kp < H1 && n4ok) {
+                        const size_t p = (size_t)kp * N + n4;
+                        *reinterpret_cast<f32x4*>(&mp[p]) = nm;
+                        *reinterpret_cast<f32x4*>(&vp[p]) = nv;
+                        *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
+                        *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
+                        if (tapp) *reinterpret_cast<f32x4*>(&tapp[p]) = acc[q];
+                    }
+                }
+                sub_stamp(23);
+            }
+            sub_begin();
+            // action rows of the critic's concat (rank-AD term): G[H1+j][n] = sum_b E[b][j] * D[b][n]
+            if (E != nullptr) {
+                float ge[AD];
+#pragma unroll
+                for (int j = 0; j < AD; j++) ge[j] = 0.0f;
+                for (int bb = 0; bb < MB / 4; bb++) {
+                    const int b = 4 * bb + g;
+                    float dv = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
+                    const unsigned mword = L.mask[b * NT16 + t];
+                    const float dd = ((mword >> c) & 1u) ? dv : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < AD; j++) ge[j] += E[b * AD + j] * dd;
+                }
+#pragma unroll
+                for (int j = 0; j < AD; j++) {
+                    const float gr = col4_sum(ge[j]);
+                    if (g == j && nok) {
+                        const size_t p = (size_t)(H1 + j) * N + n;
+                        float mm = mp[p], vv = vp[p];
+                        const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
+                        mp[p] = mm; vp[p] = vv; Wp[p] = nv;
+                        if (tapp) tapp[p] = gr;
+                        const float o = Wt[p];
+                        Wt[p] = o + tau * (nv - o);
                     }
                 }
             }
+            sub_stamp(24);
         }
     }
 };
@@ -508,22 +572,47 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     float* v_c = dv.v_c + (size_t)agent * d.Ppad;
     float* pw = dv.pw + agent * 4;
     const float lr_a = dv.actor_lr[agent], lr_c = dv.critic_lr[agent], tau = dv.tau;
+#ifdef RLC_STAMPS
+    float* stamp_buf = grad_taps ? dv.tap_gc + (size_t)agent * d.Ppad : nullptr;   // diagnostic build: no gradient taps
+    float* tap_gc = nullptr;
+    float* tap_ga = nullptr;
+#else
     float* tap_gc = grad_taps ? dv.tap_gc + (size_t)agent * d.Ppad : nullptr;
     float* tap_ga = grad_taps ? dv.tap_ga + (size_t)agent * d.Ppad : nullptr;
+#endif
     float amax[AD];
 #pragma unroll
     for (int j = 0; j < AD; j++) amax[j] = dv.amax[j];
 
     // zero the padded tails of the per-sample vectors once (rows >= B never change afterwards)
     for (int i = tid; i < MB * AD; i += kThreads) { L.a[i] = 0.f; L.aout[i] = 0.f; L.mu[i] = 0.f; L.dz[i] = 0.f; }
-    for (int i = tid; i < MB * S; i += kThreads) { L.x[i] = 0.f; L.x2[i] = 0.f; }
+    for (int i = tid; i < MB * SMAX; i += kThreads) { L.x[i] = 0.f; L.x2[i] = 0.f; }
     for (int i = tid; i < MB; i += kThreads) { L.q[i] = 0.f; L.y[i] = 0.f; L.dq[i] = 0.f; }
     for (int i = tid; i < MB * NT16; i += kThreads) L.mask[i] = 0;
     __syncthreads();
 
     f32x4 acc[MT][NTW];
+#ifdef RLC_STAMPS
+    // diagnostic build only: phase boundaries in shader cycles, written where the critic gradient tap lives
+    long long t_prev = clock64();
+    int stamp_i = 0;
+#define STAMP()                                                                                  \
+    do {                                                                                         \
+        if (tid == 0 && stamp_buf) { const long long t = clock64(); stamp_buf[stamp_i] += (float)(t - t_prev); t_prev = t; } \
+        stamp_i++;                                                                               \
+    } while (0)
+    if (stamp_buf) for (int i = tid; i < 64; i += kThreads) stamp_buf[i] = 0.0f;
+    const long long t_k0 = clock64(), w_k0 = wall_clock64();
+    u.stamp_buf = stamp_buf;
+    __syncthreads();
+#else
+#define STAMP() do {} while (0)
+#endif
 
     for (int upd = 0; upd < n_updates; upd++) {
+#ifdef RLC_STAMPS
+        stamp_i = 0;
+#endif
         // Re-materialise lane geometry every update: without this hipcc hoists the address arithmetic of
         // all ~15 phases out of the update loop and then spills it (190 scratch stores in the prologue).
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));
@@ -550,26 +639,30 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                 L.r[b] = dv.rr[slot]; L.g[b] = dv.rg[slot];
             }
             for (int i = 0; i < S; i++) {
-                L.x[b * S + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
-                L.x2[b * S + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x[b * SMAX + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x2[b * SMAX + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
             }
 #pragma unroll
             for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
         }
         __syncthreads();
+        STAMP();
 
         // ================= steps 1-2: target networks on s' (DDPG.py:77) =================
         u.trunk(tt + d.oW1, tt + d.ob1, L.x2);
         __syncthreads();
+        STAMP();
         u.fwd_gemm(acc, tt + d.oWa2, HA, H1);
         u.bias_relu(acc, tt + d.oba2, HA, nullptr, nullptr);
         u.template row_dot<false>(acc, HA, tt + d.oWa3, AD, 1, nullptr);          // z' partials
         __syncthreads();
+        STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
             L.aout[i] = tanhf(u.part_sum(b, j) + tt[d.oba3 + j]) * amax[j];
         }
         __syncthreads();
+        STAMP();
         u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
         u.bias_relu(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2 + (size_t)H1 * HC);
         // q' partials: only column j = 0 of the partial buffer is meaningful here
@@ -578,6 +671,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             u.template row_dot<false>(acc, HC, tt + d.oWc3, 1, 0, nullptr);
         }
         __syncthreads();
+        STAMP();
         for (int b = tid; b < B; b += kThreads) {
             const float qt = u.part_sum(b, 0) + tt[d.obc3];
             const float y = (float)(L.r[b] + L.g[b] * (double)qt);     // float64 TD glue (DDPG.py:80-84)
@@ -585,15 +679,18 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             dv.tap_y[(size_t)agent * RLC_MAX_BATCH + b] = y;
         }
         __syncthreads();
+        STAMP();
 
         // ================= step 3: critic step =================
         u.trunk(th + d.oW1, th + d.ob1, L.x);
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < HC ? th[d.oWc3 + n] : 0.0f;
         __syncthreads();
+        STAMP();
         u.fwd_gemm(acc, th + d.oWc2, HC, H1);
         u.bias_relu(acc, th + d.obc2, HC, L.a, th + d.oWc2 + (size_t)H1 * HC);
         u.template row_dot<false>(acc, HC, th + d.oWc3, 1, 0, nullptr);           // q partials
         __syncthreads();
+        STAMP();
         for (int b = tid; b < B; b += kThreads) {
             const float q = u.part_sum(b, 0) + th[d.obc3];
             L.q[b] = q;
@@ -601,6 +698,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             L.dq[b] = 2.0f * (q - L.y[b]) / (float)B;                  // d mean((y-q)^2)/dq
         }
         __syncthreads();
+        STAMP();
         // wave-local column reductions from the live g2 accumulators: dWc3, dbc2; then the relu masks
         float g_wc3[NTW], g_bc2[NTW];
         {
@@ -627,12 +725,15 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         }
         u.store_masks(acc, HC);
         __syncthreads();
+        STAMP();
         // dh1 = (dg2 . Wc2[:H1]^T) * relu'(h1) -> W1/b1 gradients -> critic Adam on the trunk (Q1)
         const float alpha_c = adam_alpha(lr_c, pw[2], pw[3]);
         u.template bwd_gemm<1>(acc, th + d.oWc2, HC, H1, L.dq);
         __syncthreads();      // every wave has finished reading the pre-step Wc2 rows and W1
+        STAMP();
 #ifndef RLC_EXP_NOTRUNKG
         u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f);
+        STAMP();
 #endif
         // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue
 #ifndef RLC_EXP_NOWGRAD
@@ -670,6 +771,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             }
         }
         __syncthreads();
+        STAMP();
         if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
 
         // ================= step 4: actor forward with the updated trunk (DDPG.py:90) =================
@@ -679,11 +781,13 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             L.wvec[i] = n < HA ? th[d.oWa3 + n * AD + j] : 0.0f;       // Wa3 transposed [j][n]
         }
         __syncthreads();
+        STAMP();
         u.fwd_gemm(acc, th + d.oWa2, HA, H1);
         u.bias_relu(acc, th + d.oba2, HA, nullptr, nullptr);
         u.template row_dot<false>(acc, HA, th + d.oWa3, AD, 1, nullptr);          // z partials
         u.store_masks(acc, HA);
         __syncthreads();
+        STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
             const float mu = tanhf(u.part_sum(b, j) + th[d.oba3 + j]);
@@ -693,6 +797,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             dv.tap_aout[(size_t)agent * RLC_MAX_BATCH * AD + i] = ao;
         }
         __syncthreads();
+        STAMP();
         // the h2 accumulators are needed again for dWa3 once dz is known: park them in registers
         f32x4 h2acc[MT][NTW];
 #pragma unroll
@@ -709,6 +814,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         // dqda[b][j] = sum_n step(g2[b][n]) * Wc3[n] * Wc2[H1+j][n]
         u.template row_dot<true>(acc, HC, th + d.oWc2 + (size_t)H1 * HC, 1, HC, th + d.oWc3);
         __syncthreads();
+        STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
             const float dqda = u.part_sum(b, j);
@@ -717,6 +823,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             L.dz[i] = -dqda * (1.0f - mu * mu);                         // grad_ys = -dQ/da on tanh output (Q3)
         }
         __syncthreads();
+        STAMP();
 
         // ================= step 6: actor step =================
         float g_wa3[NTW][AD], g_ba2[NTW];
@@ -754,8 +861,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         const float alpha_a = adam_alpha(lr_a, pw[0], pw[1]);
         u.template bwd_gemm<AD>(acc, th + d.oWa2, HA, H1, L.dz);
         __syncthreads();
+        STAMP();
 #ifndef RLC_EXP_NOTRUNKG
         u.trunk_grad_adam(acc, th, m_a, v_a, alpha_a, d.oW1, d.ob1, tap_ga, tt, tau);
+        STAMP();
 #endif
 #ifndef RLC_EXP_NOWGRAD
         u.template wgrad_adam<AD>(L.dz, nullptr, H1, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
@@ -795,9 +904,16 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             }
         }
         __syncthreads();
+        STAMP();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
         __syncthreads();
     }
+#ifdef RLC_STAMPS
+    if (tid == 0 && stamp_buf) {
+        stamp_buf[40] = (float)(clock64() - t_k0);
+        stamp_buf[41] = (float)(wall_clock64() - w_k0);
+    }
+#endif
 }
 
 template <int MT, int AD>

@@ -204,6 +204,14 @@ __device__ __forceinline__ float adam_step(float var, float g, float& m, float& 
     return var - (m * alpha) / (sqrtf(v) + 1e-8f);
 }
 
+// same update with the hardware sqrt / reciprocal (1 ulp each) instead of the IEEE-exact expansions:
+// ~10 VALU instead of ~30 per element; relative deviation ~2e-7, far inside the 1e-5 parity bar
+__device__ __forceinline__ float adam_step_fast(float var, float g, float& m, float& v, float alpha) {
+    m += (g - m) * (1.0f - 0.9f);
+    v += (g * g - v) * (1.0f - 0.999f);
+    return var - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + 1e-8f);
+}
+
 __device__ __forceinline__ float adam_alpha(float lr, float b1p, float b2p) {
     return lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
 }
