@@ -16,7 +16,7 @@
 //         weight-gradient GEMM straight from the accumulators
 //
 // Tiling: batch rows on the MFMA M axis (MT = ceil(B/16) tiles), features on N; wave w of 8 owns
-// N-tiles w and w+8 for ALL M tiles, so reductions over the batch (bias / W3 / W1 gradients)
+// the ADJACENT N-tiles 2w and 2w+1 (one 128-byte line per weight row) for ALL M tiles, so reductions over the batch (bias / W3 / W1 gradients)
 // are wave-local and only reductions over features (q, z, dQ/da) cross waves through LDS partials,
 // summed in a fixed order (deterministic: K updates in one launch == K launches, bit for bit).
 // fp32 in / fp32 accumulate MFMA is a k-ordered fmaf chain (exact fp32), so the 1e-5 parity bar holds.
@@ -172,7 +172,7 @@ struct Upd {
         bool own[NTW], cval[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = wave + kWaves * i;
+            const int t = NTW * wave + i;
             own[i] = t < NT;
             col[i] = 16 * t + c;
             cval[i] = own[i] && col[i] < N;
@@ -182,7 +182,7 @@ struct Upd {
 #pragma unroll
             for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        float bcur[NTW][4], bnxt[NTW][4];
+        float bcur[NTW][4], bnxt[NTW][4], bnx2[NTW][4];   // weights in flight: this chunk + two ahead
         auto loadB = [&](float (&dst)[NTW][4], int kc) {
             const int k0 = kc + 4 * g;
             const bool kval = k0 < K;
@@ -193,8 +193,9 @@ struct Upd {
                     dst[i][s] = (kval && cval[i]) ? W[(size_t)(k0 + s) * N + col[i]] : 0.0f;
         };
         loadB(bcur, 0);
+        loadB(bnxt, 16);
         for (int kc = 0; kc < K; kc += 16) {
-            loadB(bnxt, kc + 16);      // past-the-end chunks load zeros (predicated off)
+            loadB(bnx2, kc + 32);      // past-the-end chunks load zeros (predicated off)
             const bool kval = kc + 4 * g < K;
             f32x4 av[MT];
 #pragma unroll
@@ -213,7 +214,7 @@ struct Upd {
 #pragma unroll
             for (int i = 0; i < NTW; i++)
 #pragma unroll
-                for (int s = 0; s < 4; s++) bcur[i][s] = bnxt[i][s];
+                for (int s = 0; s < 4; s++) { bcur[i][s] = bnxt[i][s]; bnxt[i][s] = bnx2[i][s]; }
         }
     }
 
@@ -223,7 +224,7 @@ struct Upd {
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = wave + kWaves * i;
+            const int t = NTW * wave + i;
             const int n = 16 * t + c;
             const bool ok = t < NT && n < N;
             const float bs = ok ? bias[n] : 0.0f;
@@ -253,7 +254,7 @@ struct Upd {
         float cf[NTW][AD];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = wave + kWaves * i;
+            const int t = NTW * wave + i;
             const int n = 16 * t + c;
             const bool ok = t < NT && n < N;
 #pragma unroll
@@ -293,7 +294,7 @@ struct Upd {
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = wave + kWaves * i;
+            const int t = NTW * wave + i;
             if (t < NT) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
@@ -319,7 +320,7 @@ struct Upd {
         bool own[NTW], rval[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = wave + kWaves * i;
+            const int t = NTW * wave + i;
             own[i] = t < NT;
             row[i] = 16 * t + c;
             rval[i] = own[i] && row[i] < Kout;
@@ -334,7 +335,7 @@ struct Upd {
 #pragma unroll
             for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
 
-        f32x4 bcur[NTW], bnxt[NTW];
+        f32x4 bcur[NTW], bnxt[NTW], bnx2[NTW];
         auto loadB = [&](f32x4 (&dst)[NTW], int nc) {
             const int n0 = nc + 4 * g;
             const bool nval = n0 < Nk;
@@ -344,8 +345,9 @@ struct Upd {
                                            : f32x4{0.f, 0.f, 0.f, 0.f};
         };
         loadB(bcur, 0);
+        loadB(bnxt, 16);
         for (int nc = 0; nc < Nk; nc += 16) {
-            loadB(bnxt, nc + 16);      // past-the-end chunks load zeros (predicated off)
+            loadB(bnx2, nc + 32);      // past-the-end chunks load zeros (predicated off)
             const int n0 = nc + 4 * g;
             const bool nval = n0 < Nk;
             f32x4 wv[NS];
@@ -373,7 +375,7 @@ struct Upd {
                         for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], bcur[i][s], acc[mt][i]);
                     }
 #pragma unroll
-            for (int i = 0; i < NTW; i++) bcur[i] = bnxt[i];
+            for (int i = 0; i < NTW; i++) { bcur[i] = bnxt[i]; bnxt[i] = bnx2[i]; }
         }
     }
 
@@ -384,7 +386,7 @@ struct Upd {
         const int NT = (H1 + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = wave + kWaves * i;
+            const int t = NTW * wave + i;
             if (t >= NT) continue;
             const int k = 16 * t + c;
             float gb = 0.0f;
@@ -440,7 +442,7 @@ struct Upd {
         const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the trunk units; action rows below
         const int gperm = ((g & 1) << 1) | (g >> 1);     // 0,2,1,3
         for (int i = 0; i < NTW; i++) {
-            const int t = wave + kWaves * i;
+            const int t = NTW * wave + i;
             if (t >= NT) break;
             const int n = 16 * t + c;
             const bool nok = n < N;
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HC + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = u.wave + kWaves * i;
+                const int t = NTW * u.wave + i;
                 const int n = 16 * t + u.c;
                 const float w3 = (t < NT && n < HC) ? L.wvec[n] : 0.0f;
                 float s3 = 0.0f, s2 = 0.0f;
@@ -745,7 +747,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HC + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = u.wave + kWaves * i;
+                const int t = NTW * u.wave + i;
                 const int n = 16 * t + u.c;
                 if (t < NT && n < HC && u.g < 2) {
                     const int p = (u.g == 0) ? d.oWc3 + n : d.obc2 + n;
@@ -758,16 +760,20 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                     tt[p] = o + tau * (nv - o);
                 }
             }
-            if (tid == 0) {
+            if (u.wave == 0) {            // bc3: sum_b dq[b] by one wave (fixed-order shuffle tree)
                 float gr = 0.0f;
-                for (int b = 0; b < B; b++) gr += L.dq[b];
-                const int p = d.obc3;
-                float mm = m_c[p], vv = v_c[p];
-                const float nv = adam_step(th[p], gr, mm, vv, alpha_c);
-                m_c[p] = mm; v_c[p] = vv; th[p] = nv;
-                if (tap_gc) tap_gc[p] = gr;
-                const float o = tt[p];
-                tt[p] = o + tau * (nv - o);
+                for (int b = u.lane; b < MB; b += 64) gr += L.dq[b];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) gr += __shfl_xor(gr, off, 64);
+                if (u.lane == 0) {
+                    const int p = d.obc3;
+                    float mm = m_c[p], vv = v_c[p];
+                    const float nv = adam_step(th[p], gr, mm, vv, alpha_c);
+                    m_c[p] = mm; v_c[p] = vv; th[p] = nv;
+                    if (tap_gc) tap_gc[p] = gr;
+                    const float o = tt[p];
+                    tt[p] = o + tau * (nv - o);
+                }
             }
         }
         __syncthreads();
@@ -831,7 +837,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HA + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = u.wave + kWaves * i;
+                const int t = NTW * u.wave + i;
                 const int n = 16 * t + u.c;
                 const bool ok = t < NT && n < HA;
                 float w3[AD], s3[AD];
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HA + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = u.wave + kWaves * i;
+                const int t = NTW * u.wave + i;
                 const int n = 16 * t + u.c;
                 if (t < NT && n < HA && u.g <= AD) {
                     // lane group 0 -> ba2[n]; groups 1..AD -> Wa3[n][j]
@@ -891,16 +897,21 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                     tt[p] = o + tau * (nv - o);
                 }
             }
-            if (tid < AD) {
+            if (u.wave < AD) {            // ba3[j]: sum_b dz[b][j], wave j
+                const int j = u.wave;
                 float gr = 0.0f;
-                for (int b = 0; b < B; b++) gr += L.dz[b * AD + tid];
-                const int p = d.oba3 + tid;
-                float mm = m_a[p], vv = v_a[p];
-                const float nv = adam_step(th[p], gr, mm, vv, alpha_a);
-                m_a[p] = mm; v_a[p] = vv; th[p] = nv;
-                if (tap_ga) tap_ga[p] = gr;
-                const float o = tt[p];
-                tt[p] = o + tau * (nv - o);
+                for (int b = u.lane; b < MB; b += 64) gr += L.dz[b * AD + j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) gr += __shfl_xor(gr, off, 64);
+                if (u.lane == 0) {
+                    const int p = d.oba3 + j;
+                    float mm = m_a[p], vv = v_a[p];
+                    const float nv = adam_step(th[p], gr, mm, vv, alpha_a);
+                    m_a[p] = mm; v_a[p] = vv; th[p] = nv;
+                    if (tap_ga) tap_ga[p] = gr;
+                    const float o = tt[p];
+                    tt[p] = o + tau * (nv - o);
+                }
             }
         }
         __syncthreads();
