@@ -1,51 +1,53 @@
-// ddpg_mfma.hip -- fused DDPG update on gfx950 fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+// ddpg_mfma3_kernel.h -- fused DDPG update on gfx950 fp32 matrix cores, "trunk on the fly" form.
 //
-// Same contract as ddpg_generic.hip (one workgroup per agent, n_updates sequential updates per
-// launch, every update = sample + gather + agents/DDPG.py:74-95), but the nine [B,200]x[200,200]-class
-// contractions of one update run on MFMA tiles and nothing [B,H]-sized ever leaves the CU:
+// Same contract as ddpg_generic.hip (one workgroup per agent, n_updates sequential updates per launch,
+// every update = sample + gather + agents/DDPG.py:74-95) and the same math as ddpg_mfma_kernel.h, but the
+// shared first layer h1 = relu(x.W1 + b1) (hydra_ddpg_network.py:100-107; S inputs, S <= 8) is never
+// stored: wherever a GEMM needs h1 as an MFMA operand, or its relu mask, it is recomputed from the
+// per-sample state vectors staged in LDS (S FMAs + max per element, hidden under the 32-cycle MFMAs).
+// Dropping the [B,H1] fp32 LDS image (90 KB at B=100, H=200) shrinks a workgroup to ~20 KB of LDS and
+// 4 waves, so TWO agents are resident per CU: while one streams its Adam state through the memory-bound
+// weight-gradient epilogue (per-CU HBM rate ~22 GB/s) the other keeps the matrix pipe busy with the
+// MFMA-bound forward/backward GEMMs.  An update moves ~3.7 MB per CU (168 us at that rate) and needs
+// ~170 us of MFMA issue; only overlapping the two gets under their sum.
 //
-//   LDS   hbuf   fp32 [MT*16][LDH]   the trunk activation h1 (target / online / post-critic-step), the
-//                                    A operand of every forward GEMM and of both weight-gradient GEMMs
-//         mask16 u16  [MT*16][16]    relu masks of g2 / h2, one bit per unit: dg2 = mask*dq*Wc3 and
-//                                    dh2 = mask*(dz.Wa3) are rank-A outer products, regenerated on the
-//                                    fly as MFMA operands instead of being stored as [B,H] fp32
-//         per-sample vectors (x, x', a, y, q, dq, mu, dz ...), row-reduction partials, a staged Wc3/Wa3
-//   VGPR  accumulators of the GEMM in flight (MT x 4 tiles of 16x16), weight fragments streamed
-//         global -> VGPR (each weight element is read once per GEMM per agent; no LDS staging)
-//   HBM   theta, theta', Adam m/v: Wa2/Wc2 are updated (Adam + Polyak) in the epilogue of their
-//         weight-gradient GEMM straight from the accumulators
+//   LDS   x, x' [MB][SP] (per-sample state vectors, rows padded to 4 or 8 floats), W1|b1 staged [SP+1][256],
+//         relu masks of g2 / h2 as 16-bit words (dg2, dh2 regenerated as MFMA operands), per-sample
+//         vectors, row-reduction partials, staged Wc3 / Wa3^T
+//   VGPR  accumulators of the GEMM in flight (MT x 4 tiles of 16x16 per wave), weight fragments streamed
+//         global -> VGPR, prefetched W/m/v/W' of the weight-gradient chunk in flight
+//   HBM   theta, theta', Adam m/v; h2 is parked for one GEMM in a per-agent scratch (written and re-read
+//         by the same lanes as 16-byte vectors, L2-resident)
 //
-// Tiling: batch rows on the MFMA M axis (MT = ceil(B/16) tiles), features on N; wave w of 8 owns
-// the ADJACENT N-tiles 2w and 2w+1 (one 128-byte line per weight row) for ALL M tiles, so reductions over the batch (bias / W3 / W1 gradients)
-// are wave-local and only reductions over features (q, z, dQ/da) cross waves through LDS partials,
-// summed in a fixed order (deterministic: K updates in one launch == K launches, bit for bit).
-// fp32 in / fp32 accumulate MFMA is a k-ordered fmaf chain (exact fp32), so the 1e-5 parity bar holds.
+// Tiling: batch rows on the MFMA M axis, features on N; wave w of 4 owns N-tiles {w, w+4, w+8, w+12} for
+// ALL M tiles: batch reductions are wave-local, feature reductions go through fixed-order LDS partials
+// (deterministic).  fp32-in/fp32-accumulate MFMA is an exact fp32 fmaf chain, so the 1e-5 bar holds.
 //
 // Supported shapes: S <= 8, A in {1,2}, H1/HA/HC multiples of 4 in [16,256], B <= 128.
 #pragma once
 #include "rlc_common.h"
 
-namespace {
+namespace mf3 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 512;
-constexpr int kWaves = 8;     // two waves per SIMD: one can issue MFMA while the other does VALU / waits on loads
-constexpr int NTW = 2;        // N tiles per wave  (N <= 256)
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int NTW = 4;        // N tiles per wave (N <= 256)
 constexpr int NT16 = 16;      // mask words per row
-constexpr int MC = 7;         // M' tiles per chunk in the weight-gradient GEMMs
+constexpr int LDW = 256;      // row length of the staged W1|b1 image
 constexpr int SMAX = 8;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// sum over the 16 lanes that share lane>>4 (rotate-reduce with DPP row_ror: every lane gets the sum)
 template <int ROR>
 __device__ __forceinline__ float dpp_ror_add(float x) {
     const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + ROR, 0xf, 0xf, false);
     return x + __int_as_float(y);
 }
+// sum over the 16 lanes that share lane>>4 (every lane gets the sum)
 __device__ __forceinline__ float row16_sum(float x) {
     x = dpp_ror_add<8>(x);
     x = dpp_ror_add<4>(x);
@@ -61,41 +63,35 @@ __device__ __forceinline__ float col4_sum(float x) {
 }
 
 struct Smem {
-    float* hbuf;
+    float *xs, *x2s;   // [MB][SP]
+    float* w1s;        // [SP+1][LDW]: rows 0..SP-1 = W1 (zero rows past S), row SP = b1
     unsigned short* mask;
-    float* part;      // [kWaves][MB][AD]
-    float* wvec;      // [AD][256] staged Wc3 (row 0) or Wa3 transposed
-    float *x, *x2, *a, *aout, *mu, *dz, *q, *y, *dq;
+    float* part;       // [kWaves][MB][AD]
+    float* wvec;       // [AD][256] staged Wc3 (row 0) or Wa3 transposed
+    float *a, *aout, *mu, *dz, *q, *y, *dq;
     double *r, *g;
     long long* idx;
     int* pool;
     int* dups;
 };
 
-__host__ __device__ inline int ldh_for(int H1) {
-    // leading dimension with (LDH/4) % 16 == 2: conflict-free ds_read_b128 rows AND b32 columns
-    int q = (H1 + 3) / 4;
-    while ((q & 15) != 2) q++;
-    return q * 4;
-}
-
-__host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, unsigned char* base, Smem* out) {
+__host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, int SP, unsigned char* base, Smem* out) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         unsigned char* p = base ? base + off : nullptr;
         off += (bytes + 15) & ~(size_t)15;
         return p;
     };
-    const int MB = MT * 16, S = d.S, A = d.A, LDH = ldh_for(d.H1);
-    float* hbuf = (float*)take(sizeof(float) * MB * LDH);
+    const int MB = MT * 16, A = d.A;
     double* r = (double*)take(sizeof(double) * MB);
     double* g = (double*)take(sizeof(double) * MB);
     long long* idx = (long long*)take(sizeof(long long) * RLC_MAX_BATCH);
+    float* xs = (float*)take(sizeof(float) * MB * SP);
+    float* x2s = (float*)take(sizeof(float) * MB * SP);
+    float* w1s = (float*)take(sizeof(float) * (SP + 1) * LDW);
     unsigned short* mask = (unsigned short*)take(sizeof(unsigned short) * MB * NT16);
     float* part = (float*)take(sizeof(float) * kWaves * MB * A);
     float* wvec = (float*)take(sizeof(float) * A * 256);
-    float* x = (float*)take(sizeof(float) * MB * SMAX);      // rows padded to 8 floats: two ds_read_b128
-    float* x2 = (float*)take(sizeof(float) * MB * SMAX);
     float* a = (float*)take(sizeof(float) * MB * A);
     float* aout = (float*)take(sizeof(float) * MB * A);
     float* mu = (float*)take(sizeof(float) * MB * A);
@@ -106,20 +102,23 @@ __host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, unsigned 
     int* pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     int* dups = (int*)take(sizeof(int) * 4);
     if (out) {
-        out->hbuf = hbuf; out->r = r; out->g = g; out->idx = idx; out->mask = mask; out->part = part;
-        out->wvec = wvec; out->x = x; out->x2 = x2; out->a = a; out->aout = aout; out->mu = mu; out->dz = dz;
+        out->r = r; out->g = g; out->idx = idx; out->xs = xs; out->x2s = x2s; out->w1s = w1s; out->mask = mask;
+        out->part = part; out->wvec = wvec; out->a = a; out->aout = aout; out->mu = mu; out->dz = dz;
         out->q = q; out->y = y; out->dq = dq; out->pool = pool; out->dups = dups;
     }
     return off;
 }
 
-template <int MT, int AD>
+// floats of per-agent global scratch needed to park the h2 accumulators
+__host__ __device__ inline size_t park_floats(int MT) { return (size_t)kWaves * MT * NTW * 64 * 4; }
+
+template <int MT, int AD, int SP>
 struct Upd {
     static constexpr int MB = MT * 16;
+    static constexpr int MC = (SP == 4) ? 7 : 4;    // M' tiles per chunk of the weight-gradient GEMM
 
-    // per-thread geometry
     int tid, lane, wave, c, g;
-    int S, H1, HA, HC, B, LDH;
+    int S, H1, HA, HC, B;
     Smem L;
 #ifdef RLC_STAMPS
     float* stamp_buf = nullptr;
@@ -133,46 +132,49 @@ struct Upd {
     __device__ __forceinline__ void sub_stamp(int) {}
 #endif
 
-    // ---------------------------------------------------------------------------------------
-    // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
-    // ---------------------------------------------------------------------------------------
-    __device__ __forceinline__ void trunk(const float* W1, const float* b1, const float* xs) {
-        // 256 column slots x 2 row halves
-        const int half = tid >> 8;
-        for (int k = tid & 255; k < LDH; k += 256) {
-            float w[SMAX];
-            float bias = 0.0f;
-            const bool live = k < H1;
+    // ---- the trunk, recomputed wherever it is needed.  ONE expression order everywhere, so the forward
+    // value, its relu mask in the backward pass and the operand of the weight-gradient GEMM agree bit for bit.
+    __device__ __forceinline__ static float trunk1(const float (&x)[SP], const float (&w)[SP], float bias) {
+        float acc = 0.0f;
 #pragma unroll
-            for (int i = 0; i < SMAX; i++) w[i] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
-            if (live) bias = b1[k];
-#pragma unroll 4
-            for (int b = half * (MB / 2); b < (half + 1) * (MB / 2); b++) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(&xs[b * SMAX]);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(&xs[b * SMAX + 4]);
-                float acc = 0.0f;      // same i-order as the scalar form; padded lanes multiply by w = 0
+        for (int i = 0; i < SP; i++) acc = __builtin_fmaf(x[i], w[i], acc);
+        return fmaxf(acc + bias, 0.0f);
+    }
+    __device__ __forceinline__ void load_xrow(const float* xsrc, int b, float (&x)[SP]) const {
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc += x0[i] * w[i];
+        for (int v = 0; v < SP / 4; v++) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&xsrc[b * SP + 4 * v]);
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc += x1[i] * w[4 + i];
-                acc = fmaxf(acc + bias, 0.0f);
-                L.hbuf[b * LDH + k] = (live && b < B) ? acc : 0.0f;
+            for (int e = 0; e < 4; e++) x[4 * v + e] = t[e];
+        }
+    }
+
+    // stage W1 | b1 (global) into LDS; all threads, caller syncs
+    __device__ __forceinline__ void stage_trunk(const float* W1, const float* b1) {
+        for (int i = tid; i < (SP + 1) * LDW; i += kThreads) {
+            const int row = i / LDW, k = i % LDW;
+            float v = 0.0f;
+            if (k < H1) {
+                if (row == SP) v = b1[k];
+                else if (row < S) v = W1[row * H1 + k];
             }
+            L.w1s[i] = v;
         }
     }
 
     // ---------------------------------------------------------------------------------------
-    // forward GEMM: acc[mt][i] (tile rows 16mt.., cols 16*(wave+4i)..) = hbuf[:, 0:K] . W[0:K, :]
-    // A: one ds_read_b128 per M tile per 16-deep chunk, lane (c,g) holds k = kc+4g+s for step s;
-    // B: W[(kc+4g+s)*N + col] streamed global -> VGPR, next chunk prefetched under the MFMAs.
+    // forward GEMM: acc[mt][i] = h1(xsrc)[:, 0:K] . W[0:K, cols of tile wave+4i],  K = H1.
+    // A fragments are generated from the x rows and the staged trunk columns (lane (c,g) holds
+    // k = kc+4g+s for step s); B = W[(kc+4g+s)*N + col] streamed global -> VGPR one chunk ahead.
     // ---------------------------------------------------------------------------------------
-    __device__ __forceinline__ void fwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int N, int K) {
+    __device__ __forceinline__ void fwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int N, const float* xsrc) {
+        const int K = H1;
         const int NT = (N + 15) >> 4;
         int col[NTW];
         bool own[NTW], cval[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = wave + kWaves * i;
             own[i] = t < NT;
             col[i] = 16 * t + c;
             cval[i] = own[i] && col[i] < N;
@@ -182,7 +184,7 @@ struct Upd {
 #pragma unroll
             for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        float bcur[NTW][4], bnxt[NTW][4], bnx2[NTW][4];   // weights in flight: this chunk + two ahead
+        float bcur[NTW][4], bnxt[NTW][4];
         auto loadB = [&](float (&dst)[NTW][4], int kc) {
             const int k0 = kc + 4 * g;
             const bool kval = k0 < K;
@@ -193,15 +195,28 @@ struct Upd {
                     dst[i][s] = (kval && cval[i]) ? W[(size_t)(k0 + s) * N + col[i]] : 0.0f;
         };
         loadB(bcur, 0);
-        loadB(bnxt, 16);
         for (int kc = 0; kc < K; kc += 16) {
-            loadB(bnx2, kc + 32);      // past-the-end chunks load zeros (predicated off)
-            const bool kval = kc + 4 * g < K;
+            loadB(bnxt, kc + 16);      // past-the-end chunks load zeros (predicated off)
+            const int k0 = kc + 4 * g;
+            const bool kval = k0 < K;
+            const int k0c = kval ? k0 : 0;
+            // trunk columns k0..k0+3: W1 rows and the bias, 16-byte LDS reads (zero rows beyond S)
+            f32x4 wk[SP];
+#pragma unroll
+            for (int i = 0; i < SP; i++) wk[i] = *reinterpret_cast<const f32x4*>(&L.w1s[i * LDW + k0c]);
+            const f32x4 bk = *reinterpret_cast<const f32x4*>(&L.w1s[SP * LDW + k0c]);
             f32x4 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(&L.hbuf[(16 * mt + c) * LDH + kc + 4 * g]);
-                av[mt] = kval ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+                float x[SP];
+                load_xrow(xsrc, 16 * mt + c, x);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    float w[SP];
+#pragma unroll
+                    for (int i = 0; i < SP; i++) w[i] = wk[i][s];
+                    av[mt][s] = kval ? trunk1(x, w, bk[s]) : 0.0f;
+                }
             }
 #pragma unroll
             for (int s = 0; s < 4; s++)
@@ -214,7 +229,7 @@ struct Upd {
 #pragma unroll
             for (int i = 0; i < NTW; i++)
 #pragma unroll
-                for (int s = 0; s < 4; s++) { bcur[i][s] = bnxt[i][s]; bnxt[i][s] = bnx2[i][s]; }
+                for (int s = 0; s < 4; s++) bcur[i][s] = bnxt[i][s];
         }
     }
 
@@ -224,7 +239,7 @@ struct Upd {
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = wave + kWaves * i;
             const int n = 16 * t + c;
             const bool ok = t < NT && n < N;
             const float bs = ok ? bias[n] : 0.0f;
@@ -254,7 +269,7 @@ struct Upd {
         float cf[NTW][AD];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = wave + kWaves * i;
             const int n = 16 * t + c;
             const bool ok = t < NT && n < N;
 #pragma unroll
@@ -294,7 +309,7 @@ struct Upd {
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = wave + kWaves * i;
             if (t < NT) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
@@ -307,10 +322,26 @@ struct Upd {
         }
     }
 
+    // park / restore the accumulators in the agent's global scratch (same lanes write and read: no fence)
+    __device__ __forceinline__ void park(const f32x4 (&acc)[MT][NTW], float* sc) const {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+                *reinterpret_cast<f32x4*>(&sc[((size_t)(wave * MT + mt) * NTW + i) * 256 + lane * 4]) = acc[mt][i];
+    }
+    __device__ __forceinline__ void unpark(f32x4 (&acc)[MT][NTW], const float* sc) const {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++)
+                acc[mt][i] = *reinterpret_cast<const f32x4*>(&sc[((size_t)(wave * MT + mt) * NTW + i) * 256 + lane * 4]);
+    }
+
     // ---------------------------------------------------------------------------------------
     // backward-to-input GEMM: acc[b][k'] = sum_n D[b][n] * W[k'][n],  D[b][n] = mask(b,n) * sum_j seed[b][j]*wv[j][n]
     // (D is never materialised).  k-dim = n in chunks of 16 with lane (c,g) taking n = nc+4g+s:
-    //   A  from mask16 + seed (registers) + wvec (LDS);  B = one dwordx4 of row k' of W per chunk.
+    //   A  from mask16 + seed (registers) + wvec (LDS);  B = one 16-byte piece of row k' of W per chunk.
     // ---------------------------------------------------------------------------------------
     template <int NS>
     __device__ __forceinline__ void bwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int Nk /* row length = k-dim */,
@@ -320,7 +351,7 @@ struct Upd {
         bool own[NTW], rval[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = wave + kWaves * i;
             own[i] = t < NT;
             row[i] = 16 * t + c;
             rval[i] = own[i] && row[i] < Kout;
@@ -335,7 +366,7 @@ struct Upd {
 #pragma unroll
             for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
 
-        f32x4 bcur[NTW], bnxt[NTW], bnx2[NTW];
+        f32x4 bcur[NTW], bnxt[NTW];
         auto loadB = [&](f32x4 (&dst)[NTW], int nc) {
             const int n0 = nc + 4 * g;
             const bool nval = n0 < Nk;
@@ -345,9 +376,8 @@ struct Upd {
                                            : f32x4{0.f, 0.f, 0.f, 0.f};
         };
         loadB(bcur, 0);
-        loadB(bnxt, 16);
         for (int nc = 0; nc < Nk; nc += 16) {
-            loadB(bnx2, nc + 32);      // past-the-end chunks load zeros (predicated off)
+            loadB(bnxt, nc + 16);      // past-the-end chunks load zeros (predicated off)
             const int n0 = nc + 4 * g;
             const bool nval = n0 < Nk;
             f32x4 wv[NS];
@@ -375,47 +405,53 @@ struct Upd {
                         for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], bcur[i][s], acc[mt][i]);
                     }
 #pragma unroll
-            for (int i = 0; i < NTW; i++) { bcur[i] = bnxt[i]; bnxt[i] = bnx2[i]; }
+            for (int i = 0; i < NTW; i++) bcur[i] = bnxt[i];
         }
     }
 
-    // epilogue of bwd_gemm: dh1 = acc * (hbuf > 0); column-reduce into the W1 / b1 gradients of this wave's
-    // trunk units and apply Adam (+ optional Polyak) right here.
+    // epilogue of bwd_gemm: dh1 = acc * relu'(h1) with h1's sign recomputed from x and the STAGED trunk
+    // (the weights the forward pass used); column-reduce into the W1 / b1 gradients of this wave's trunk
+    // units and apply Adam (+ optional Polyak) right here.
     __device__ __forceinline__ void trunk_grad_adam(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
                                                     float alpha, int oW1, int ob1, float* tap, float* tt, float tau) {
         const int NT = (H1 + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = wave + kWaves * i;
             if (t >= NT) continue;
             const int k = 16 * t + c;
-            float gb = 0.0f;
-            float gw[SMAX];
+            const int kc_ = k < H1 ? k : 0;
+            float wcol[SP];
 #pragma unroll
-            for (int s = 0; s < SMAX; s++) gw[s] = 0.0f;
+            for (int s = 0; s < SP; s++) wcol[s] = L.w1s[s * LDW + kc_];
+            const float bias = L.w1s[SP * LDW + kc_];
+            float gb = 0.0f;
+            float gw[SP];
+#pragma unroll
+            for (int s = 0; s < SP; s++) gw[s] = 0.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int b = 16 * mt + 4 * g + r;
-                    const float hv = L.hbuf[b * LDH + (k < H1 ? k : 0)];
+                    float x[SP];
+                    load_xrow(L.xs, b, x);
+                    const float hv = trunk1(x, wcol, bias);
                     const float d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] : 0.0f;
                     gb += d;
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(&L.x[b * SMAX]);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&L.x[b * SMAX + 4]);
 #pragma unroll
-                    for (int s = 0; s < 4; s++) { gw[s] += x0[s] * d; gw[4 + s] += x1[s] * d; }
+                    for (int s = 0; s < SP; s++) gw[s] += x[s] * d;
                 }
             gb = col4_sum(gb);
 #pragma unroll
-            for (int s = 0; s < SMAX; s++) gw[s] = col4_sum(gw[s]);
-            // lanes g == s' handle row s' (spread the Adam work over the 4 lane groups)
+            for (int s = 0; s < SP; s++) gw[s] = col4_sum(gw[s]);
+            // lane group g handles rows g, g+4, ... (row S = the bias)
             if (k < H1) {
                 for (int s = g; s <= S; s += 4) {
                     const bool is_bias = s == S;
                     float gr = gb;
 #pragma unroll
-                    for (int q = 0; q < SMAX; q++)
+                    for (int q = 0; q < SP; q++)
                         if (q == s && !is_bias) gr = gw[q];
                     const int p = is_bias ? ob1 + k : oW1 + s * H1 + k;
                     float mm = m[p], vv = v[p];
@@ -430,35 +466,33 @@ struct Upd {
 
     // ---------------------------------------------------------------------------------------
     // weight-gradient GEMM + Adam (+Polyak) epilogue:
-    //   G[k'][n] = sum_b X[b][k'] * D[b][n],  X = [hbuf | E] (E = action columns, or none), D as above.
-    // Output rows k' on the MFMA M axis (A operand = hbuf read as columns), cols n owned per wave;
-    // k-dim = batch, lane group g takes b = 16*bt + 4*s + {0,2,1,3}[g] (bank-conflict-free b32 reads).
+    //   G[k'][n] = sum_b h1[b][k'] * D[b][n]  (+ action rows E below), D as above.
+    // TRANSPOSED tiles: acc[q][r] = G[k' = 16(m0+q) + c][n = 16t + 4g + r] (D^T on the A side, h1 -- recomputed
+    // from x and the staged trunk -- on the B side), so each lane owns 4 CONSECUTIVE n of one weight row and
+    // the W / m / v / W' traffic is one 16-byte load (prefetched before the k-loop) + one 16-byte store per array.
+    // k-dim = batch: lane group g takes b = 4*ks + {0,2,1,3}[g].
     // ---------------------------------------------------------------------------------------
     template <int NS>
     __device__ __forceinline__ void wgrad_adam(const float* seed /* LDS [MB][NS] */, const float* E /* LDS [MB][AD] or null */,
-                                               int Krows /* H1 (+AD if E) */, int N, float* Wp, float* mp, float* vp,
-                                               float alpha, float* tapp, float* Wt, float tau) {
+                                               int N, float* Wp, float* mp, float* vp, float alpha, float* tapp,
+                                               float* Wt, float tau) {
         const int NT = (N + 15) >> 4;
-        const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the trunk units; action rows below
+        const int NMT = (H1 + 15) >> 4;
         const int gperm = ((g & 1) << 1) | (g >> 1);     // 0,2,1,3
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = wave + kWaves * i;
             if (t >= NT) break;
             const int n = 16 * t + c;
             const bool nok = n < N;
             float wvn[NS];
 #pragma unroll
             for (int j = 0; j < NS; j++) wvn[j] = nok ? L.wvec[j * 256 + n] : 0.0f;
+            const int n4 = 16 * t + 4 * g;
+            const bool n4ok = n4 < N;                 // N % 4 == 0: all four columns valid or none
             for (int m0 = 0; m0 < NMT; m0 += MC) {
-                // TRANSPOSED tile: acc[q][r] = G[k' = 16(m0+q) + c][n = 16t + 4g + r], i.e. D^T on the A side and
-                // hbuf on the B side, so that each lane owns 4 CONSECUTIVE n of one weight row: the
-                // W / m / v / W' traffic of the Adam epilogue is one 16-byte load + one 16-byte store per array.
                 f32x4 acc[MC];
-                // Prefetch this chunk's W / m / v / W' NOW: their HBM latency hides under the k-loop's MFMAs
-                // instead of serialising in the epilogue (addresses clamped, stores predicated).
                 f32x4 pw_[MC], pm_[MC], pv_[MC], pt_[MC];
-                const int n4 = 16 * t + 4 * g;
-                const bool n4ok = n4 < N;                 // N % 4 == 0: all four columns valid or none
+                float wq[MC][SP], bq[MC];
                 sub_begin();
 #pragma unroll
                 for (int q = 0; q < MC; q++) {
@@ -469,23 +503,27 @@ struct Upd {
                     pm_[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
                     pv_[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
                     pt_[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
+                    const int kpc = kp < H1 ? kp : 0;
+#pragma unroll
+                    for (int s = 0; s < SP; s++) wq[q][s] = L.w1s[s * LDW + kpc];
+                    bq[q] = L.w1s[SP * LDW + kpc];
                 }
                 sub_stamp(21);
-#pragma unroll 4
+#pragma unroll 2
                 for (int ks = 0; ks < MT * 4; ks++) {
                     const int b = 4 * ks + gperm;
-                    // D[b][n] for this lane's (b, n = 16t + c)
                     float dv = 0.0f;
 #pragma unroll
                     for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
                     const unsigned mword = L.mask[b * NT16 + t];
                     const float df = ((mword >> c) & 1u) ? dv : 0.0f;
-                    // hbuf fragments: branch-free (clamped address + select) so the LDS reads issue together
+                    float x[SP];
+                    load_xrow(L.xs, b, x);
                     float hf[MC];
 #pragma unroll
                     for (int q = 0; q < MC; q++) {
                         const int kp = 16 * (m0 + q) + c;
-                        const float hv = L.hbuf[b * LDH + (kp < H1 ? kp : 0)];
+                        const float hv = trunk1(x, wq[q], bq[q]);
                         hf[q] = kp < H1 ? hv : 0.0f;
                     }
 #pragma unroll
@@ -549,19 +587,19 @@ struct Upd {
     }
 };
 
-template <int MT, int AD>
-__global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev dv, int first_agent, int n_updates,
-                                                                        int source, const long long* host_idx,
-                                                                        int grad_taps, int stagger) {
+template <int MT, int AD, int SP>
+__global__ __launch_bounds__(kThreads, 2) void rlc_ddpg_update_mfma3_kernel(RlcDev dv, int first_agent, int n_updates,
+                                                                            int source, const long long* host_idx,
+                                                                            int grad_taps, int stagger) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using U = Upd<MT, AD>;
+    using U = Upd<MT, AD, SP>;
     constexpr int MB = U::MB;
     const RlcDims d = dv.d;
     U u;
     u.tid = threadIdx.x; u.lane = u.tid & 63; u.wave = __builtin_amdgcn_readfirstlane(u.tid >> 6);
     u.c = u.lane & 15; u.g = u.lane >> 4;
-    u.S = d.S; u.H1 = d.H1; u.HA = d.HA; u.HC = d.HC; u.B = d.B; u.LDH = ldh_for(d.H1);
-    smem_carve(d, MT, smem, &u.L);
+    u.S = d.S; u.H1 = d.H1; u.HA = d.HA; u.HC = d.HC; u.B = d.B;
+    smem_carve(d, MT, SP, smem, &u.L);
     Smem& L = u.L;
     const int tid = u.tid, S = d.S, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
     const int agent = first_agent + blockIdx.x;
@@ -573,6 +611,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     float* m_c = dv.m_c + (size_t)agent * d.Ppad;
     float* v_c = dv.v_c + (size_t)agent * d.Ppad;
     float* pw = dv.pw + agent * 4;
+    float* park_sc = dv.scratch + (size_t)agent * dv.scratch_stride;
     const float lr_a = dv.actor_lr[agent], lr_c = dv.critic_lr[agent], tau = dv.tau;
 #ifdef RLC_STAMPS
     float* stamp_buf = grad_taps ? dv.tap_gc + (size_t)agent * d.Ppad : nullptr;   // diagnostic build: no gradient taps
@@ -586,16 +625,19 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #pragma unroll
     for (int j = 0; j < AD; j++) amax[j] = dv.amax[j];
 
-    // zero the padded tails of the per-sample vectors once (rows >= B never change afterwards)
+    // zero the padded tails once (rows >= B never change afterwards: their seeds dq / dz stay 0, so whatever
+    // the recomputed trunk yields for them never reaches a gradient)
     for (int i = tid; i < MB * AD; i += kThreads) { L.a[i] = 0.f; L.aout[i] = 0.f; L.mu[i] = 0.f; L.dz[i] = 0.f; }
-    for (int i = tid; i < MB * SMAX; i += kThreads) { L.x[i] = 0.f; L.x2[i] = 0.f; }
+    for (int i = tid; i < MB * SP; i += kThreads) { L.xs[i] = 0.f; L.x2s[i] = 0.f; }
     for (int i = tid; i < MB; i += kThreads) { L.q[i] = 0.f; L.y[i] = 0.f; L.dq[i] = 0.f; }
     for (int i = tid; i < MB * NT16; i += kThreads) L.mask[i] = 0;
     __syncthreads();
 
-    // All agents do the same work, so started together every CU would hit the memory-bound weight-gradient
-    // epilogues at the same moment (HBM saturated chip-wide) and the MFMA-bound GEMMs at the same moment
-    // (HBM idle).  A one-time start offset per workgroup, spread over one update period, de-phases the CUs.
+    // Two agents share a CU.  Started together they would run the same phase at the same time (both on
+    // the matrix pipe, then both on the memory pipe); delaying every second workgroup once by about half
+    // an update puts one agent's memory-bound weight-gradient epilogues under the other's GEMMs.
+    // The same offset, spread over 16 slots of one update period, also de-phases the CUs: otherwise the whole
+    // chip hits the memory-bound epilogues at once (HBM saturated) and the GEMMs at once (HBM idle).
     if (stagger > 0) {
         const int slots = (int)((blockIdx.x * 11u) & 15u) * stagger;
         for (int i = 0; i < slots; i++) __builtin_amdgcn_s_sleep(127);
@@ -603,7 +645,6 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 
     f32x4 acc[MT][NTW];
 #ifdef RLC_STAMPS
-    // diagnostic build only: phase boundaries in shader cycles, written where the critic gradient tap lives
     long long t_prev = clock64();
     int stamp_i = 0;
 #define STAMP()                                                                                  \
@@ -624,7 +665,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         stamp_i = 0;
 #endif
         // Re-materialise lane geometry every update: without this hipcc hoists the address arithmetic of
-        // all ~15 phases out of the update loop and then spills it (190 scratch stores in the prologue).
+        // all phases out of the update loop and then spills it.
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));
         // ================= sample + gather (utils/replaybuffer.py:32-37) =================
         const RlcRingMeta ring = dv.ring[agent];
@@ -649,58 +690,49 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                 L.r[b] = dv.rr[slot]; L.g[b] = dv.rg[slot];
             }
             for (int i = 0; i < S; i++) {
-                L.x[b * SMAX + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
-                L.x2[b * SMAX + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.xs[b * SP + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x2s[b * SP + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
             }
 #pragma unroll
             for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
         }
+        u.stage_trunk(tt + d.oW1, tt + d.ob1);                                     // target trunk
         __syncthreads();
-        STAMP();
+        STAMP();   // 0 sample+gather
 
         // ================= steps 1-2: target networks on s' (DDPG.py:77) =================
-        u.trunk(tt + d.oW1, tt + d.ob1, L.x2);
-        __syncthreads();
-        STAMP();
-        u.fwd_gemm(acc, tt + d.oWa2, HA, H1);
+        u.fwd_gemm(acc, tt + d.oWa2, HA, L.x2s);
         u.bias_relu(acc, tt + d.oba2, HA, nullptr, nullptr);
         u.template row_dot<false>(acc, HA, tt + d.oWa3, AD, 1, nullptr);          // z' partials
         __syncthreads();
-        STAMP();
+        STAMP();   // 1 G1
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
             L.aout[i] = tanhf(u.part_sum(b, j) + tt[d.oba3 + j]) * amax[j];
         }
         __syncthreads();
-        STAMP();
-        u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
+        u.fwd_gemm(acc, tt + d.oWc2, HC, L.x2s);
         u.bias_relu(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2 + (size_t)H1 * HC);
-        // q' partials: only column j = 0 of the partial buffer is meaningful here
-        {
-            // reuse row_dot with coef = Wc3' (stride 1, js 0 -> every j gets the same value)
-            u.template row_dot<false>(acc, HC, tt + d.oWc3, 1, 0, nullptr);
-        }
+        u.template row_dot<false>(acc, HC, tt + d.oWc3, 1, 0, nullptr);           // q' partials (column j = 0)
         __syncthreads();
-        STAMP();
+        STAMP();   // 2 G2
         for (int b = tid; b < B; b += kThreads) {
             const float qt = u.part_sum(b, 0) + tt[d.obc3];
             const float y = (float)(L.r[b] + L.g[b] * (double)qt);     // float64 TD glue (DDPG.py:80-84)
             L.y[b] = y;
             dv.tap_y[(size_t)agent * RLC_MAX_BATCH + b] = y;
         }
-        __syncthreads();
-        STAMP();
-
-        // ================= step 3: critic step =================
-        u.trunk(th + d.oW1, th + d.ob1, L.x);
+        u.stage_trunk(th + d.oW1, th + d.ob1);                                     // online trunk
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < HC ? th[d.oWc3 + n] : 0.0f;
         __syncthreads();
-        STAMP();
-        u.fwd_gemm(acc, th + d.oWc2, HC, H1);
+        STAMP();   // 3 y + staging
+
+        // ================= step 3: critic step =================
+        u.fwd_gemm(acc, th + d.oWc2, HC, L.xs);
         u.bias_relu(acc, th + d.obc2, HC, L.a, th + d.oWc2 + (size_t)H1 * HC);
         u.template row_dot<false>(acc, HC, th + d.oWc3, 1, 0, nullptr);           // q partials
         __syncthreads();
-        STAMP();
+        STAMP();   // 4 G3
         for (int b = tid; b < B; b += kThreads) {
             const float q = u.part_sum(b, 0) + th[d.obc3];
             L.q[b] = q;
@@ -708,14 +740,13 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             L.dq[b] = 2.0f * (q - L.y[b]) / (float)B;                  // d mean((y-q)^2)/dq
         }
         __syncthreads();
-        STAMP();
         // wave-local column reductions from the live g2 accumulators: dWc3, dbc2; then the relu masks
         float g_wc3[NTW], g_bc2[NTW];
         {
             const int NT = (HC + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.wave + kWaves * i;
                 const int n = 16 * t + u.c;
                 const float w3 = (t < NT && n < HC) ? L.wvec[n] : 0.0f;
                 float s3 = 0.0f, s2 = 0.0f;
@@ -735,27 +766,23 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         }
         u.store_masks(acc, HC);
         __syncthreads();
-        STAMP();
+        STAMP();   // 5 dq, dWc3, masks
         // dh1 = (dg2 . Wc2[:H1]^T) * relu'(h1) -> W1/b1 gradients -> critic Adam on the trunk (Q1)
         const float alpha_c = adam_alpha(lr_c, pw[2], pw[3]);
         u.template bwd_gemm<1>(acc, th + d.oWc2, HC, H1, L.dq);
-        __syncthreads();      // every wave has finished reading the pre-step Wc2 rows and W1
-        STAMP();
-#ifndef RLC_EXP_NOTRUNKG
+        __syncthreads();      // every wave has finished reading the pre-step Wc2 rows
+        STAMP();   // 6 G5
         u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f);
-        STAMP();
-#endif
-        // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue
-#ifndef RLC_EXP_NOWGRAD
-        u.template wgrad_adam<1>(L.dq, L.a, H1 + AD, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
-                     tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau);
-#endif
-        // small critic tensors: Wc3, bc2 (column owners), bc3 (one thread)
+        STAMP();   // 7 trunk grad
+        // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue (h1 from the STAGED pre-step trunk)
+        u.template wgrad_adam<1>(L.dq, L.a, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
+                                 tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau);
+        // small critic tensors: Wc3, bc2 (column owners), bc3 (one wave)
         {
             const int NT = (HC + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.wave + kWaves * i;
                 const int n = 16 * t + u.c;
                 if (t < NT && n < HC && u.g < 2) {
                     const int p = (u.g == 0) ? d.oWc3 + n : d.obc2 + n;
@@ -785,23 +812,23 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             }
         }
         __syncthreads();
-        STAMP();
+        STAMP();   // 8 G4 + small
         if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
 
         // ================= step 4: actor forward with the updated trunk (DDPG.py:90) =================
-        u.trunk(th + d.oW1, th + d.ob1, L.x);
+        u.stage_trunk(th + d.oW1, th + d.ob1);                                     // post-critic-step trunk
         for (int i = tid; i < AD * 256; i += kThreads) {
             const int j = i / 256, n = i % 256;
             L.wvec[i] = n < HA ? th[d.oWa3 + n * AD + j] : 0.0f;       // Wa3 transposed [j][n]
         }
         __syncthreads();
-        STAMP();
-        u.fwd_gemm(acc, th + d.oWa2, HA, H1);
+        u.fwd_gemm(acc, th + d.oWa2, HA, L.xs);
         u.bias_relu(acc, th + d.oba2, HA, nullptr, nullptr);
         u.template row_dot<false>(acc, HA, th + d.oWa3, AD, 1, nullptr);          // z partials
         u.store_masks(acc, HA);
+        u.park(acc, park_sc);                 // h2 is needed again for dWa3 once dz is known
         __syncthreads();
-        STAMP();
+        STAMP();   // 9 G6
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
             const float mu = tanhf(u.part_sum(b, j) + th[d.oba3 + j]);
@@ -811,41 +838,30 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             dv.tap_aout[(size_t)agent * RLC_MAX_BATCH * AD + i] = ao;
         }
         __syncthreads();
-        STAMP();
-        // the h2 accumulators are needed again for dWa3 once dz is known: park them in registers
-        f32x4 h2acc[MT][NTW];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int i = 0; i < NTW; i++) h2acc[mt][i] = acc[mt][i];
-#ifdef RLC_EXP_NOPARK
-#define h2acc acc
-#endif
 
         // ================= step 5: dQ/da at the scaled action, updated critic (DDPG.py:91) =================
-        u.fwd_gemm(acc, th + d.oWc2, HC, H1);
+        u.fwd_gemm(acc, th + d.oWc2, HC, L.xs);
         u.bias_relu(acc, th + d.obc2, HC, L.aout, th + d.oWc2 + (size_t)H1 * HC);
         // dqda[b][j] = sum_n step(g2[b][n]) * Wc3[n] * Wc2[H1+j][n]
         u.template row_dot<true>(acc, HC, th + d.oWc2 + (size_t)H1 * HC, 1, HC, th + d.oWc3);
         __syncthreads();
-        STAMP();
+        STAMP();   // 10 G7
         for (int i = tid; i < B * AD; i += kThreads) {
-            const int b = i / AD, j = i % AD;
-            const float dqda = u.part_sum(b, j);
+            const float dqda = u.part_sum(i / AD, i % AD);
             dv.tap_dqda[(size_t)agent * RLC_MAX_BATCH * AD + i] = dqda;
             const float mu = L.mu[i];
             L.dz[i] = -dqda * (1.0f - mu * mu);                         // grad_ys = -dQ/da on tanh output (Q3)
         }
         __syncthreads();
-        STAMP();
 
         // ================= step 6: actor step =================
         float g_wa3[NTW][AD], g_ba2[NTW];
         {
+            u.unpark(acc, park_sc);           // h2 back in the accumulators
             const int NT = (HA + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.wave + kWaves * i;
                 const int n = 16 * t + u.c;
                 const bool ok = t < NT && n < HA;
                 float w3[AD], s3[AD];
@@ -857,7 +873,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int b = 16 * mt + 4 * u.g + r;
-                        const float hv = h2acc[mt][i][r];
+                        const float hv = acc[mt][i][r];
                         float dd = 0.0f;
 #pragma unroll
                         for (int j = 0; j < AD; j++) {
@@ -875,20 +891,16 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         const float alpha_a = adam_alpha(lr_a, pw[0], pw[1]);
         u.template bwd_gemm<AD>(acc, th + d.oWa2, HA, H1, L.dz);
         __syncthreads();
-        STAMP();
-#ifndef RLC_EXP_NOTRUNKG
+        STAMP();   // 11 dz, dWa3, G9
         u.trunk_grad_adam(acc, th, m_a, v_a, alpha_a, d.oW1, d.ob1, tap_ga, tt, tau);
-        STAMP();
-#endif
-#ifndef RLC_EXP_NOWGRAD
-        u.template wgrad_adam<AD>(L.dz, nullptr, H1, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
-                     tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau);
-#endif
+        STAMP();   // 12 trunk grad (actor)
+        u.template wgrad_adam<AD>(L.dz, nullptr, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
+                                  tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau);
         {
             const int NT = (HA + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.wave + kWaves * i;
                 const int n = 16 * t + u.c;
                 if (t < NT && n < HA && u.g <= AD) {
                     // lane group 0 -> ba2[n]; groups 1..AD -> Wa3[n][j]
@@ -923,7 +935,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             }
         }
         __syncthreads();
-        STAMP();
+        STAMP();   // 13 G8 + small
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
         __syncthreads();
     }
@@ -933,25 +945,21 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         stamp_buf[41] = (float)(wall_clock64() - w_k0);
     }
 #endif
+#undef STAMP
 }
 
-template <int MT, int AD>
+template <int MT, int AD, int SP>
 int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
-             int grad_taps, hipStream_t st) {
-    const size_t lds = smem_carve(dv.d, MT, nullptr, nullptr);
-    RLC_REQUIRE(lds <= 160 * 1024, "MFMA DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = rlc_ddpg_update_mfma_kernel<MT, AD>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    // de-phase the CUs only when a launch is long enough to amortise the offset (<= one update period)
-    const int stagger = (n_agents > 16 && n_updates >= 8) ? dv.stagger : 0;
-    hipLaunchKernelGGL(kern, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates, source, idx_dev,
-                       grad_taps, stagger);
+             int grad_taps, int stagger, hipStream_t st) {
+    const size_t lds = smem_carve(dv.d, MT, SP, nullptr, nullptr);
+    RLC_REQUIRE(lds <= 64 * 1024, "MFMA DDPG kernel needs %zu B of LDS (> 64 KiB)", lds);
+    RLC_REQUIRE((size_t)dv.scratch_stride >= park_floats(MT), "per-agent scratch too small for the h2 park");
+    // de-phase only when a launch is long enough to amortise the offset (<= one update period)
+    const int stg = (n_agents > 16 && n_updates >= 8) ? stagger : 0;
+    hipLaunchKernelGGL((rlc_ddpg_update_mfma3_kernel<MT, AD, SP>), dim3(n_agents), dim3(kThreads), lds, st, dv,
+                       first_agent, n_updates, source, idx_dev, grad_taps, stg);
     RLC_HIP(hipGetLastError());
     return 0;
 }
 
-}  // namespace
+}  // namespace mf3

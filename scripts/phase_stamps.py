@@ -10,15 +10,23 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params  # noqa: E402
 
-NAMES = ["sample+gather", "trunk(target)", "G1 actor' fwd", "a' tanh", "G2 critic' fwd", "TD target", "trunk(online)",
+NAMES_HBUF = ["sample+gather", "trunk(target)", "G1 actor' fwd", "a' tanh", "G2 critic' fwd", "TD target", "trunk(online)",
          "G3 critic fwd", "dq", "dWc3/dbc2+masks", "G5 dh1 (bwd)", "trunk grad+Adam", "G4 dWc2+Adam+small", "trunk(new)",
          "G6 actor fwd", "mu tanh", "G7 critic(mu) fwd", "dz", "G9 dh1 (bwd)", "trunk grad+Adam (a)", "G8 dWa2+Adam+small"]
 
 
+NAMES_V3 = ["sample+gather+stage", "G1 actor' fwd", "G2 critic' fwd", "TD target+stage", "G3 critic fwd", "dq,dWc3,masks",
+            "G5 dh1 (bwd)", "trunk grad+Adam", "G4 dWc2+Adam+small", "G6 actor fwd+park", "G7 critic(mu) fwd",
+            "dz,dWa3,G9 (bwd)", "trunk grad+Adam (a)", "G8 dWa2+Adam+small"]
+
+
 def main():
-    NA, U, N = int(os.environ.get("NA", "256")), 8, 200000
+    KERN = os.environ.get("KERN", "mfma")
+    NAMES = NAMES_V3 if KERN == "mfma" else NAMES_HBUF
+    NA, U, N = int(os.environ.get("NA", "512" if KERN == "mfma" else "256")), 8, 200000
     pop = DDPGPopulation(NA, 3, 1, 200, 200, 200, 100, N, 0.01, [-1, -1, -8], [1, 1, 8], [-2.0], [2.0], 1e-3, 1e-2,
                          seeds=np.arange(NA) + 1)
+    pop.set_kernel(KERN)
     pop.enable_grad_taps(True)
     rng = np.random.RandomState(0)
     data = (rng.randn(N, 3), rng.randn(N, 1), rng.randn(N), rng.randn(N, 3), np.full(N, 0.99))
