@@ -90,9 +90,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--agents", type=int, default=512, help="independent agents per GPU (2 per CU)")
-    ap.add_argument("--updates-per-step", type=int, default=16, help="updates of every agent per launch")
-    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma", "mfma_hbuf"])
+    ap.add_argument("--agents", type=int, default=256, help="independent agents per GPU (one per CU)")
+    ap.add_argument("--updates-per-step", type=int, default=32, help="updates of every agent per launch")
+    ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()

@@ -15,12 +15,10 @@ STAMPS = os.environ.get("RLC_STAMPS", "0") == "1"
 OBJ = os.path.join(CSRC, ("_obj_stamps" if STAMPS else "_obj") + ("_fast" if os.environ.get("RLC_FAST_BUILD", "0") == "1" else ""))
 OUT = os.path.join(_HERE, "librlcontrol_hip_stamps.so" if STAMPS else "librlcontrol_hip.so")
 PLAIN = ("rlc_api.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip")
-MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]                          # hbuf kernel
-MFMA3_VARIANTS = [(mt, ad, sp) for sp in (4, 8) for ad in (1, 2) for mt in (2, 4, 7, 8)]      # on-the-fly trunk
+MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]
 FAST = os.environ.get("RLC_FAST_BUILD", "0") == "1"     # developer loop: only the headline shape
 if FAST:
     MFMA_VARIANTS = [(7, 1)]
-    MFMA3_VARIANTS = [(7, 1, 4)]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DRLC_STAMPS"] if STAMPS else [])
 if os.environ.get("RLC_FAST_BUILD", "0") == "1":
     CFLAGS.append("-DRLC_ONLY_7_1")
@@ -41,9 +39,6 @@ def _units():
     for mt, ad in MFMA_VARIANTS:
         units.append((os.path.join(CSRC, "ddpg_mfma_inst.hip"), os.path.join(OBJ, "ddpg_mfma_%d_%d.o" % (mt, ad)),
                       ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
-    for mt, ad, sp in MFMA3_VARIANTS:
-        units.append((os.path.join(CSRC, "ddpg_mfma3_inst.hip"), os.path.join(OBJ, "ddpg_mfma3_%d_%d_%d.o" % (mt, ad, sp)),
-                      ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad, "-DRLC_SP=%d" % sp]))
     return units
 
 

@@ -552,7 +552,7 @@ struct Upd {
 template <int MT, int AD>
 __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev dv, int first_agent, int n_updates,
                                                                         int source, const long long* host_idx,
-                                                                        int grad_taps, int stagger) {
+                                                                        int grad_taps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using U = Upd<MT, AD>;
     constexpr int MB = U::MB;
@@ -592,14 +592,6 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     for (int i = tid; i < MB; i += kThreads) { L.q[i] = 0.f; L.y[i] = 0.f; L.dq[i] = 0.f; }
     for (int i = tid; i < MB * NT16; i += kThreads) L.mask[i] = 0;
     __syncthreads();
-
-    // All agents do the same work, so started together every CU would hit the memory-bound weight-gradient
-    // epilogues at the same moment (HBM saturated chip-wide) and the MFMA-bound GEMMs at the same moment
-    // (HBM idle).  A one-time start offset per workgroup, spread over one update period, de-phases the CUs.
-    if (stagger > 0) {
-        const int slots = (int)((blockIdx.x * 11u) & 15u) * stagger;
-        for (int i = 0; i < slots; i++) __builtin_amdgcn_s_sleep(127);
-    }
 
     f32x4 acc[MT][NTW];
 #ifdef RLC_STAMPS
@@ -946,10 +938,8 @@ int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int
         RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    // de-phase the CUs only when a launch is long enough to amortise the offset (<= one update period)
-    const int stagger = (n_agents > 16 && n_updates >= 8) ? dv.stagger : 0;
     hipLaunchKernelGGL(kern, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates, source, idx_dev,
-                       grad_taps, stagger);
+                       grad_taps);
     RLC_HIP(hipGetLastError());
     return 0;
 }

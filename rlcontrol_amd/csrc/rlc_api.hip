@@ -188,15 +188,7 @@ int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out) {
     TRY(dmalloc(h, &dv.tap_aout, NA * RLC_MAX_BATCH * A));
     TRY(dmalloc(h, &dv.tap_dqda, NA * RLC_MAX_BATCH * A));
     dv.tap_gc = nullptr; dv.tap_ga = nullptr;
-    {
-        size_t need = rlc_generic_scratch_floats(dv.d);
-        if (rlc_mfma_supported(dv.d) && rlc_mfma_scratch_floats(dv.d) > need) need = rlc_mfma_scratch_floats(dv.d);
-        dv.scratch_stride = (long long)((need + 63) & ~(size_t)63);
-    }
-    {
-        const char* e = getenv("RLC_STAGGER");       // tuning knob; default = about half an update at the headline shape
-        dv.stagger = e ? atoi(e) : 8;      // x 8128 cycles per slot, 16 slots ~ one update period
-    }
+    dv.scratch_stride = (long long)((rlc_generic_scratch_floats(dv.d) + 63) & ~(size_t)63);
     TRY(dmalloc(h, &dv.scratch, NA * (size_t)dv.scratch_stride, false));
 #undef TRY
 
@@ -502,7 +494,7 @@ int rlc_ddpg_qval(rlc_ddpg* h, int32_t agent, int32_t n, const double* states, c
 
 // -------------------------------------------------------------------------------------- learning
 static int pick_variant(const rlc_ddpg* h) {
-    if (h->variant >= 1 && h->variant <= 3) return h->variant;
+    if (h->variant == 1 || h->variant == 2) return h->variant;
     return rlc_mfma_supported(h->dv.d) ? 2 : 1;
 }
 
@@ -512,7 +504,6 @@ static int launch_update(rlc_ddpg* h, int first, int n, int n_updates, int sourc
         RLC_REQUIRE(rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
         return rlc_launch_ddpg_update_mfma(h->dv, first, n, n_updates, source, idx_dev, h->grad_taps, h->st);
     }
-    if (v == 3) return rlc_launch_ddpg_update_mfma_hbuf(h->dv, first, n, n_updates, source, idx_dev, h->grad_taps, h->st);
     return rlc_launch_ddpg_update_generic(h->dv, first, n, n_updates, source, idx_dev, h->grad_taps, h->st);
 }
 
@@ -573,9 +564,8 @@ int rlc_ddpg_update_batch(rlc_ddpg* h, int32_t agent, int32_t batch, const doubl
 
 int rlc_ddpg_set_kernel(rlc_ddpg* h, int32_t variant) {
     RLC_REQUIRE(h, "null handle");
-    RLC_REQUIRE(variant >= 0 && variant <= 3, "kernel variant must be 0 (auto), 1 (generic), 2 (mfma) or 3 (mfma_hbuf)");
+    RLC_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (auto), 1 (generic) or 2 (mfma)");
     RLC_REQUIRE(variant != 2 || rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
-    RLC_REQUIRE(variant != 3 || rlc_mfma_hbuf_supported(h->dv.d), "MFMA (hbuf) kernel does not support these dimensions");
     h->variant = variant;
     return 0;
 }

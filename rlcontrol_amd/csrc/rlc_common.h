@@ -83,7 +83,6 @@ struct RlcDev {
     int clip_state;
     float tau;
     float ou_theta, ou_mu, ou_sigma;
-    int stagger;                 // s_sleep(127) iterations every second workgroup waits once (two agents per CU)
     // networks + optimizer state: [n_agents][Ppad]
     float *theta, *theta_t, *m_a, *v_a, *m_c, *v_c;
     float* pw;                   // [n_agents][4] beta powers {a1,a2,c1,c2}
@@ -117,12 +116,9 @@ int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agen
                                    const long long* idx_dev, int grad_taps, hipStream_t st);
 // MFMA-tiled fused update (dims must satisfy rlc_mfma_supported)
 bool rlc_mfma_supported(const RlcDims& d);
-bool rlc_mfma_hbuf_supported(const RlcDims& d);
-size_t rlc_mfma_scratch_floats(const RlcDims& d);
 int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
                                 const long long* idx_dev, int grad_taps, hipStream_t st);
-int rlc_launch_ddpg_update_mfma_hbuf(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                                     const long long* idx_dev, int grad_taps, hipStream_t st);
+
 // acting / evaluation
 int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states_dev, float* out_dev, int explore,
                    hipStream_t st);

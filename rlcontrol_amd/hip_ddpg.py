@@ -45,7 +45,7 @@ def init_params(S, A, H1, HA, HC, seed):
 class DDPGPopulation(object):
     BLOB = {"theta": 0, "theta_target": 1, "actor_m": 2, "actor_v": 3, "critic_m": 4, "critic_v": 5}
     TAP = {"q": 0, "y": 1, "a_out": 2, "dqda": 3, "grads_c": 4, "grads_a": 5}
-    KERNEL = {"auto": 0, "generic": 1, "mfma": 2, "mfma_hbuf": 3}
+    KERNEL = {"auto": 0, "generic": 1, "mfma": 2}
 
     def __init__(self, n_agents, state_dim, action_dim, shared_l1_dim, actor_l2_dim, critic_l2_dim, batch_size,
                  buffer_size, tau, state_min, state_max, action_min, action_max, actor_lr, critic_lr, seeds,

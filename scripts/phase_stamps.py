@@ -15,15 +15,10 @@ NAMES_HBUF = ["sample+gather", "trunk(target)", "G1 actor' fwd", "a' tanh", "G2 
          "G6 actor fwd", "mu tanh", "G7 critic(mu) fwd", "dz", "G9 dh1 (bwd)", "trunk grad+Adam (a)", "G8 dWa2+Adam+small"]
 
 
-NAMES_V3 = ["sample+gather+stage", "G1 actor' fwd", "G2 critic' fwd", "TD target+stage", "G3 critic fwd", "dq,dWc3,masks",
-            "G5 dh1 (bwd)", "trunk grad+Adam", "G4 dWc2+Adam+small", "G6 actor fwd+park", "G7 critic(mu) fwd",
-            "dz,dWa3,G9 (bwd)", "trunk grad+Adam (a)", "G8 dWa2+Adam+small"]
-
-
 def main():
-    KERN = os.environ.get("KERN", "mfma")
-    NAMES = NAMES_V3 if KERN == "mfma" else NAMES_HBUF
-    NA, U, N = int(os.environ.get("NA", "512" if KERN == "mfma" else "256")), 8, 200000
+    KERN = "mfma"
+    NAMES = NAMES_HBUF
+    NA, U, N = int(os.environ.get("NA", "256")), 8, 200000
     pop = DDPGPopulation(NA, 3, 1, 200, 200, 200, 100, N, 0.01, [-1, -1, -8], [1, 1, 8], [-2.0], [2.0], 1e-3, 1e-2,
                          seeds=np.arange(NA) + 1)
     pop.set_kernel(KERN)
