@@ -31,7 +31,12 @@
 extern "C" {
 #endif
 
-typedef struct rlc_ddpg rlc_ddpg;
+/* One opaque handle type: a population of independent agents of ONE algorithm on one GPU.
+ * rlc_ddpg / rlc_sac name the algorithm a handle was created for; the replay, timing, sync and destroy entry
+ * points take any of them. */
+typedef struct rlc_handle rlc_handle;
+typedef rlc_handle rlc_ddpg;
+typedef rlc_handle rlc_sac;
 
 /* Mirrors what DDPG_Network_Manager.__init__ / BaseNetwork.__init__ read from Config
  * (agents/DDPG.py:17-32, agents/network/base_network.py:14-28, hydra_ddpg_network.py:9-17,
@@ -68,9 +73,9 @@ int rlc_device_count(int* out_count);
 /* -- lifetime: DDPG_Network_Manager.__init__ (agents/DDPG.py:17-32) + ReplayBuffer.__init__
  *    (utils/replaybuffer.py:16-23).  Networks start at zero; load them with rlc_ddpg_set_params. */
 int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out);
-int rlc_ddpg_destroy(rlc_ddpg* h);
+int rlc_destroy(rlc_handle* h);
 int rlc_ddpg_param_count(const rlc_ddpg* h, int64_t* out_p);
-int rlc_ddpg_sync(rlc_ddpg* h);                      /* hipStreamSynchronize on the handle's stream */
+int rlc_sync(rlc_handle* h);                         /* hipStreamSynchronize on the handle's stream */
 
 /* -- parameters / optimizer state (parity taps; also checkpointing).
  *    which: 0 online theta, 1 target theta', 2 actor-Adam m, 3 actor-Adam v, 4 critic-Adam m, 5 critic-Adam v */
@@ -84,20 +89,20 @@ int rlc_ddpg_init_target(rlc_ddpg* h, int32_t agent);
 
 /* -- replay: ReplayBuffer.add / get_size (utils/replaybuffer.py:25-30), FIFO eviction of the oldest
  *    (utils/custom_collections.py:83-101).  Logical index 0 is the OLDEST stored transition. */
-int rlc_replay_add(rlc_ddpg* h, int32_t agent, const double* state, const double* action, double reward,
+int rlc_replay_add(rlc_handle* h, int32_t agent, const double* state, const double* action, double reward,
                    const double* next_state, double transition_gamma);
-int rlc_replay_add_batch(rlc_ddpg* h, int32_t agent, int64_t n, const double* states, const double* actions,
+int rlc_replay_add_batch(rlc_handle* h, int32_t agent, int64_t n, const double* states, const double* actions,
                          const double* rewards, const double* next_states, const double* gammas);
 /* every agent receives the same n transitions, already resident in HBM as fp32/fp64 SoA (bench path) */
-int rlc_replay_fill_all_dev(rlc_ddpg* h, int64_t n, const float* s_dev, const float* a_dev,
+int rlc_replay_fill_all_dev(rlc_handle* h, int64_t n, const float* s_dev, const float* a_dev,
                             const double* r_dev, const float* s2_dev, const double* g_dev);
-int rlc_replay_size(const rlc_ddpg* h, int32_t agent, int64_t* out_size);
+int rlc_replay_size(const rlc_handle* h, int32_t agent, int64_t* out_size);
 /* ReplayBuffer.sample_batch's gather (utils/replaybuffer.py:32-37 -> custom_collections.py:37-58) for
  * caller-chosen logical indices: out arrays [k,S] [k,A] [k] [k,S] [k] float64 like the reference returns. */
-int rlc_replay_gather(rlc_ddpg* h, int32_t agent, const int64_t* logical_idx, int32_t k, double* states,
+int rlc_replay_gather(rlc_handle* h, int32_t agent, const int64_t* logical_idx, int32_t k, double* states,
                       double* actions, double* rewards, double* next_states, double* gammas);
 /* RandomAccessQueue.sample_n_k on the device (Philox; k distinct uniform logical indices in [0,size)) */
-int rlc_replay_sample_indices(rlc_ddpg* h, int32_t agent, int32_t k, int64_t* out_idx);
+int rlc_replay_sample_indices(rlc_handle* h, int32_t agent, int32_t k, int64_t* out_idx);
 
 /* -- acting: DDPG_Network_Manager.take_action's greedy part, predict_action on B=1
  *    (agents/DDPG.py:36, hydra_ddpg_network.py:162-171).  states [n][S] for agents first..first+n-1,
@@ -132,9 +137,53 @@ int rlc_ddpg_last_tap(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int
  * hydra_ddpg_network.py:37,72) of the last update -- written only while enabled (extra HBM stores). */
 int rlc_ddpg_enable_grad_taps(rlc_ddpg* h, int32_t on);
 
+
+/* ================================ SoftActorCritic (SAC-v1) ========================================
+ * Mirrors what SoftActorCritic_Network_Manager.__init__ / SoftActorCriticNetwork.__init__ read from Config
+ * (agents/SoftActorCritic.py:16-53, agents/network/sac_network.py:10-45; jsonfiles/agent/sac.json).
+ * Parameter blob (P floats), variable creation order under 'main' (sac_network.py:152-172):
+ *   pi: W1[S][L1a] b1 W2[L1a][L2a] b2 Wm[L2a][A] bm Ws[L2a][A] bs | qf: W1[S][L1c] b1 W2[L1c+A][L2c] b2 W3[L2c] b3 |
+ *   vf: W1[S][L1c] b1 W2[L1c][L2c] b2 W3[L2c] b3.      blob selector: 0 theta, 1 target, 2 Adam m, 3 Adam v. */
+typedef struct rlc_sac_config {
+    int32_t device, n_agents, state_dim, action_dim;
+    int32_t actor_l1_dim, actor_l2_dim, critic_l1_dim, critic_l2_dim;   /* jsonfiles/agent/sac.json:9-12 */
+    int32_t batch_size;      /* config.batch_size */
+    int32_t clip_state;      /* 1 when config.norm_type != 'none' (sac_network.py:207,237; Q never clips: :176) */
+    int64_t buffer_size;
+    float tau;
+    float state_min0, state_max0;   /* the SCALARS state_min[0] / state_max[0] the reference clips every dimension to */
+    float action_max0;              /* action_max[0]: scale of mu and pi (sac_network.py:160-161) */
+    const float* pi_lr;          /* [n_agents] */
+    const float* qf_vf_lr;       /* [n_agents] */
+    const float* entropy_scale;  /* [n_agents] */
+    const uint64_t* seed;        /* [n_agents] Philox keys (sampler, eps) */
+} rlc_sac_config;
+
+int rlc_sac_create(const rlc_sac_config* cfg, rlc_sac** out);
+int rlc_sac_param_count(const rlc_sac* h, int64_t* out_p);
+int rlc_sac_set_blob(rlc_sac* h, int32_t agent, int32_t which, const float* src, int64_t n);
+int rlc_sac_get_blob(rlc_sac* h, int32_t agent, int32_t which, float* dst, int64_t n);
+int rlc_sac_set_beta_powers(rlc_sac* h, int32_t agent, const float* pw4);   /* {pi b1^t, pi b2^t, value b1^t, value b2^t} */
+int rlc_sac_get_beta_powers(rlc_sac* h, int32_t agent, float* pw4);
+int rlc_sac_init_target(rlc_sac* h, int32_t agent);                       /* sac_network.py:75-76,357-358 */
+/* predict_action (sample = 0: tanh(mu)*action_max[0], sac_network.py:327-333) / sample_action (sample = 1, :336-343).
+ * eps: [n][A] N(0,1) draws standing in for tf.random_normal (:286), or NULL -> device Philox. */
+int rlc_sac_act(rlc_sac* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
+                float* out_actions);
+/* BaseAgent.learn for every agent: sample_batch + update_network + update_target_network
+ * (agents/SoftActorCritic.py:113-126).  host_indices as in rlc_ddpg_update; eps [n_agents][n_updates][batch][A] or NULL. */
+int rlc_sac_update(rlc_sac* h, int32_t n_updates, const int64_t* host_indices, const float* eps);
+/* SoftActorCritic_Network_Manager.update_network on a caller-supplied minibatch (one agent); eps [batch][A] or NULL */
+int rlc_sac_update_batch(rlc_sac* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+                         const double* next_states, const double* rewards, const double* gammas, const float* eps);
+/* taps of the last update: 0 q, 1 v, 2 logp_pi, 3 q_pi (n = batch); 4 {pi_loss, q_loss, v_loss} (n = 3) -- the
+ * fetches of train_ops (sac_network.py:135-136); 5 gradient blob (n = P, needs rlc_sac_enable_grad_taps) */
+int rlc_sac_last_tap(rlc_sac* h, int32_t agent, int32_t which, float* dst, int64_t n);
+int rlc_sac_enable_grad_taps(rlc_sac* h, int32_t on);
+
 /* -- timing on the handle's stream (hipEvents): bench.py's roofline.achieved */
-int rlc_timer_begin(rlc_ddpg* h);
-int rlc_timer_end(rlc_ddpg* h, float* out_ms);   /* synchronises on the stop event */
+int rlc_timer_begin(rlc_handle* h);
+int rlc_timer_end(rlc_handle* h, float* out_ms);   /* synchronises on the stop event */
 
 #ifdef __cplusplus
 }

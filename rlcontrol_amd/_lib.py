@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("RLCONTROL_HIP_LIB", os.path.join(_HERE, "librlcontrol
 # every symbol include/rlcontrol_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "rlc_last_error", "rlc_version", "rlc_device_count",
-    "rlc_ddpg_create", "rlc_ddpg_destroy", "rlc_ddpg_param_count", "rlc_ddpg_sync",
+    "rlc_destroy", "rlc_sync",
+    "rlc_ddpg_create", "rlc_ddpg_param_count",
     "rlc_ddpg_set_blob", "rlc_ddpg_get_blob", "rlc_ddpg_set_beta_powers", "rlc_ddpg_get_beta_powers",
     "rlc_ddpg_init_target",
     "rlc_replay_add", "rlc_replay_add_batch", "rlc_replay_fill_all_dev", "rlc_replay_size",
@@ -24,6 +25,9 @@ EXPORTS = (
     "rlc_ddpg_update", "rlc_ddpg_update_batch", "rlc_ddpg_set_kernel", "rlc_ddpg_get_kernel",
     "rlc_ddpg_last_tap", "rlc_ddpg_enable_grad_taps",
     "rlc_timer_begin", "rlc_timer_end",
+    "rlc_sac_create", "rlc_sac_param_count", "rlc_sac_set_blob", "rlc_sac_get_blob", "rlc_sac_set_beta_powers",
+    "rlc_sac_get_beta_powers", "rlc_sac_init_target", "rlc_sac_act", "rlc_sac_update", "rlc_sac_update_batch",
+    "rlc_sac_last_tap", "rlc_sac_enable_grad_taps",
 )
 
 
@@ -45,6 +49,20 @@ class rlc_ddpg_config(ctypes.Structure):
         ("seed", ctypes.POINTER(ctypes.c_uint64)),
         ("ou_theta", ctypes.c_float), ("ou_mu", ctypes.c_float), ("ou_sigma", ctypes.c_float),
         ("reserved2", ctypes.c_int32),
+    ]
+
+
+class rlc_sac_config(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("state_dim", ctypes.c_int32),
+        ("action_dim", ctypes.c_int32),
+        ("actor_l1_dim", ctypes.c_int32), ("actor_l2_dim", ctypes.c_int32), ("critic_l1_dim", ctypes.c_int32),
+        ("critic_l2_dim", ctypes.c_int32),
+        ("batch_size", ctypes.c_int32), ("clip_state", ctypes.c_int32), ("buffer_size", ctypes.c_int64),
+        ("tau", ctypes.c_float), ("state_min0", ctypes.c_float), ("state_max0", ctypes.c_float),
+        ("action_max0", ctypes.c_float),
+        ("pi_lr", ctypes.POINTER(ctypes.c_float)), ("qf_vf_lr", ctypes.POINTER(ctypes.c_float)),
+        ("entropy_scale", ctypes.POINTER(ctypes.c_float)), ("seed", ctypes.POINTER(ctypes.c_uint64)),
     ]
 
 

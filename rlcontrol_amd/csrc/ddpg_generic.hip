@@ -11,12 +11,11 @@
 // This is the any-shape path (arbitrary S, A, H1, HA, HC, B <= 128); the gfx950 matrix-core path for
 // the headline shapes is ddpg_mfma.hip.  Activations [B,H] live in a per-agent global scratch that
 // stays in the XCD's L2; per-sample vectors live in LDS.
-#include "rlc_common.h"
+#include "generic_blocks.h"
 
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kRows = 4;   // batch rows per thread-item in the dense loops
+using namespace gen;
 
 struct Lds {
     float *x, *x2, *a, *aout, *mu, *dqda, *dz, *q, *y, *dq;
@@ -57,104 +56,6 @@ __host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* bas
     return off;
 }
 
-// Y[b,n] = act( sum_k X[b,k] W[k,n] + sum_j E[b,j] W[K+j,n] + bias[n] );  act: 0 none, 1 relu, 2 tanh
-// X: [B,K] row-major (ldx); E: optional extra input columns (the action, concatenated LAST:
-// hydra_ddpg_network.py:128).  Lanes run over n (coalesced W rows); X/E reads are wave-uniform.
-__device__ void blk_dense(const float* X, int ldx, int K, const float* E, int Ke, const float* W,
-                          const float* bias, int N, float* Y, int ldy, int B, int act) {
-    const int rb = (B + kRows - 1) / kRows;
-    for (int it = threadIdx.x; it < rb * N; it += kThreads) {
-        const int n = it % N;
-        const int b0 = (it / N) * kRows;
-        float acc[kRows];
-#pragma unroll
-        for (int i = 0; i < kRows; i++) acc[i] = 0.0f;
-        for (int k = 0; k < K; k++) {
-            const float w = W[(size_t)k * N + n];
-#pragma unroll
-            for (int i = 0; i < kRows; i++) {
-                const int b = min(b0 + i, B - 1);
-                acc[i] += X[(size_t)b * ldx + k] * w;
-            }
-        }
-        for (int j = 0; j < Ke; j++) {
-            const float w = W[(size_t)(K + j) * N + n];
-#pragma unroll
-            for (int i = 0; i < kRows; i++) {
-                const int b = min(b0 + i, B - 1);
-                acc[i] += E[b * Ke + j] * w;
-            }
-        }
-        const float bs = bias[n];
-#pragma unroll
-        for (int i = 0; i < kRows; i++) {
-            if (b0 + i < B) {
-                float v = acc[i] + bs;
-                if (act == 1) v = fmaxf(v, 0.0f);
-                else if (act == 2) v = tanhf(v);
-                Y[(size_t)(b0 + i) * ldy + n] = v;
-            }
-        }
-    }
-}
-
-// dX[b,k] = (Hk[b,k] > 0) ? sum_n dY[b,n] W[k,n] : 0      (W[k][n] rows k < K only)
-__device__ void blk_dense_bwd_input(const float* dY, int N, const float* W, const float* Hk, int K, float* dX,
-                                    int B) {
-    const int rb = (B + kRows - 1) / kRows;
-    for (int it = threadIdx.x; it < rb * K; it += kThreads) {
-        const int k = it % K;
-        const int b0 = (it / K) * kRows;
-        float acc[kRows];
-#pragma unroll
-        for (int i = 0; i < kRows; i++) acc[i] = 0.0f;
-        for (int n = 0; n < N; n++) {
-            const float w = W[(size_t)k * N + n];
-#pragma unroll
-            for (int i = 0; i < kRows; i++) {
-                const int b = min(b0 + i, B - 1);
-                acc[i] += dY[(size_t)b * N + n] * w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kRows; i++)
-            if (b0 + i < B) dX[(size_t)(b0 + i) * K + k] = Hk[(size_t)(b0 + i) * K + k] > 0.0f ? acc[i] : 0.0f;
-    }
-}
-
-struct AdamCtx {
-    float* theta; float* m; float* v; float alpha; float* tap;   // tap may be null
-};
-
-__device__ __forceinline__ void adam_apply(const AdamCtx& c, int p, float g) {
-    float m = c.m[p], v = c.v[p];
-    const float nv = adam_step(c.theta[p], g, m, v, c.alpha);
-    c.m[p] = m; c.v[p] = v; c.theta[p] = nv;
-    if (c.tap) c.tap[p] = g;
-}
-
-// gradient of a dense layer's weights/bias + Adam, one parameter element per thread-item:
-//   W[k,n] (k < K): sum_b X[b,k] dY[b,n];  W[K+j,n]: sum_b E[b,j] dY[b,n];  bias[n]: sum_b dY[b,n]
-__device__ void blk_dense_grad_adam(const float* X, int ldx, int K, const float* E, int Ke, const float* dY,
-                                    int N, int B, const AdamCtx& c, int oW, int ob) {
-    const int rows = K + Ke + 1;   // last "row" is the bias
-    for (int it = threadIdx.x; it < rows * N; it += kThreads) {
-        const int n = it % N;
-        const int k = it / N;
-        float g = 0.0f;
-        if (k < K) {
-            for (int b = 0; b < B; b++) g += X[(size_t)b * ldx + k] * dY[(size_t)b * N + n];
-            adam_apply(c, oW + k * N + n, g);
-        } else if (k < K + Ke) {
-            for (int b = 0; b < B; b++) g += E[b * Ke + (k - K)] * dY[(size_t)b * N + n];
-            adam_apply(c, oW + k * N + n, g);
-        } else {
-            for (int b = 0; b < B; b++) g += dY[(size_t)b * N + n];
-            adam_apply(c, ob + n, g);
-        }
-    }
-}
-
 __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDev dv, int first_agent,
                                                                            int n_updates, int source,
                                                                            const long long* host_idx,
@@ -182,12 +83,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
 
     for (int u = 0; u < n_updates; u++) {
         // ---- sample + gather (utils/replaybuffer.py:32-37) ----
-        const RlcRingMeta ring = dv.ring[agent];
+        const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
-            const unsigned long long call = dv.sample_ctr[agent];
+            const unsigned long long call = dv.rep.sample_ctr[agent];
             __syncthreads();
-            rlc_sample_distinct(ring.size, B, dv.seed[agent], call, L.pool, L.idx, L.dups);
-            if (tid == 0) dv.sample_ctr[agent] = call + 1;
+            rlc_sample_distinct(ring.size, B, dv.rep.seed[agent], call, L.pool, L.idx, L.dups);
+            if (tid == 0) dv.rep.sample_ctr[agent] = call + 1;
         } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
             for (int b = tid; b < B; b += kThreads)
                 L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + u) * B + b];
@@ -197,12 +98,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
             const float *ps, *pa, *ps2;
             if (source == RLC_SRC_STAGING) {
                 const size_t slot = (size_t)agent * RLC_MAX_BATCH + b;
-                ps = dv.gs + slot * S; pa = dv.ga + slot * A; ps2 = dv.gs2 + slot * S;
-                L.r[b] = dv.gr[slot]; L.g[b] = dv.gg[slot];
+                ps = dv.rep.gs + slot * S; pa = dv.rep.ga + slot * A; ps2 = dv.rep.gs2 + slot * S;
+                L.r[b] = dv.rep.gr[slot]; L.g[b] = dv.rep.gg[slot];
             } else {
-                const size_t slot = (size_t)agent * dv.cap + ring_slot(ring, dv.cap, L.idx[b]);
-                ps = dv.rs + slot * S; pa = dv.ra + slot * A; ps2 = dv.rs2 + slot * S;
-                L.r[b] = dv.rr[slot]; L.g[b] = dv.rg[slot];
+                const size_t slot = (size_t)agent * dv.rep.cap + ring_slot(ring, dv.rep.cap, L.idx[b]);
+                ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot * A; ps2 = dv.rep.rs2 + slot * S;
+                L.r[b] = dv.rep.rr[slot]; L.g[b] = dv.rep.rg[slot];
             }
             for (int i = 0; i < S; i++) {
                 L.x[b * S + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
@@ -355,7 +256,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_act_kernel(RlcDev dv, int f
             if (explore) {
                 // OU: n <- n + N(mu, sigma) - theta*n ; clip(a + n)
                 const unsigned long long ctr = dv.noise_ctr[agent];
-                const Philox4 p = philox4x32_10(dv.seed[agent] ^ 0x5DEECE66Dull, ctr, (unsigned long long)(j / 2));
+                const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ 0x5DEECE66Dull, ctr, (unsigned long long)(j / 2));
                 float n0, n1;
                 philox_normal2(p, n0, n1);
                 const float z = (j & 1) ? n1 : n0;

@@ -619,12 +619,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         // all ~15 phases out of the update loop and then spills it (190 scratch stores in the prologue).
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));
         // ================= sample + gather (utils/replaybuffer.py:32-37) =================
-        const RlcRingMeta ring = dv.ring[agent];
+        const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
-            const unsigned long long call = dv.sample_ctr[agent];
+            const unsigned long long call = dv.rep.sample_ctr[agent];
             __syncthreads();
-            rlc_sample_distinct(ring.size, B, dv.seed[agent], call, L.pool, L.idx, L.dups);
-            if (tid == 0) dv.sample_ctr[agent] = call + 1;
+            rlc_sample_distinct(ring.size, B, dv.rep.seed[agent], call, L.pool, L.idx, L.dups);
+            if (tid == 0) dv.rep.sample_ctr[agent] = call + 1;
         } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
             for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + upd) * B + b];
         }
@@ -633,12 +633,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const float *ps, *pa, *ps2;
             if (source == RLC_SRC_STAGING) {
                 const size_t slot = (size_t)agent * RLC_MAX_BATCH + b;
-                ps = dv.gs + slot * S; pa = dv.ga + slot * AD; ps2 = dv.gs2 + slot * S;
-                L.r[b] = dv.gr[slot]; L.g[b] = dv.gg[slot];
+                ps = dv.rep.gs + slot * S; pa = dv.rep.ga + slot * AD; ps2 = dv.rep.gs2 + slot * S;
+                L.r[b] = dv.rep.gr[slot]; L.g[b] = dv.rep.gg[slot];
             } else {
-                const size_t slot = (size_t)agent * dv.cap + ring_slot(ring, dv.cap, L.idx[b]);
-                ps = dv.rs + slot * S; pa = dv.ra + slot * AD; ps2 = dv.rs2 + slot * S;
-                L.r[b] = dv.rr[slot]; L.g[b] = dv.rg[slot];
+                const size_t slot = (size_t)agent * dv.rep.cap + ring_slot(ring, dv.rep.cap, L.idx[b]);
+                ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot * AD; ps2 = dv.rep.rs2 + slot * S;
+                L.r[b] = dv.rep.rr[slot]; L.g[b] = dv.rep.rg[slot];
             }
             for (int i = 0; i < S; i++) {
                 L.x[b * SMAX + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);

@@ -5,7 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "rlc_common.h"
+#include "rlc_handle.h"
 
 // ------------------------------------------------------------------------------------------------
 static thread_local char g_err[1024] = "";
@@ -17,34 +17,14 @@ void rlc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-struct rlc_ddpg {
-    RlcDev dv;
-    int device;
-    hipStream_t st;
-    hipEvent_t ev0, ev1;
-    std::vector<RlcRingMeta> ring;       // host mirror of the ring metadata
-    std::vector<void*> allocs;           // every hipMalloc of this handle
-    long long* idx_dev; size_t idx_cap;  // host-index upload buffer
-    float* io_dev; size_t io_cap;        // act / qval / gather staging (device, bytes)
-    void* io_host; size_t io_host_cap;   // pinned host staging (bytes)
-    int variant;                         // requested: 0 auto, 1 generic, 2 mfma
-    int grad_taps;
-};
+
 
 namespace {
 
 template <typename T>
-int dmalloc(rlc_ddpg* h, T** out, size_t count, bool zero = true) {
-    void* p = nullptr;
-    const size_t bytes = (count ? count : 1) * sizeof(T);
-    RLC_HIP(hipMalloc(&p, bytes));
-    if (zero) RLC_HIP(hipMemsetAsync(p, 0, bytes, h->st));
-    h->allocs.push_back(p);
-    *out = (T*)p;
-    return 0;
-}
+int dmalloc(rlc_handle* h, T** out, size_t count, bool zero = true) { return rlc_h_malloc(h, out, count, zero); }
 
-int ensure_io(rlc_ddpg* h, size_t bytes) {
+int ensure_io_impl(rlc_handle* h, size_t bytes) {
     if (bytes > h->io_cap) {
         RLC_HIP(hipStreamSynchronize(h->st));
         if (h->io_dev) RLC_HIP(hipFree(h->io_dev));
@@ -66,13 +46,14 @@ int ensure_io(rlc_ddpg* h, size_t bytes) {
     return 0;
 }
 
-int check_agent(const rlc_ddpg* h, int agent) {
+int check_agent(const rlc_handle* h, int agent) {
     RLC_REQUIRE(h != nullptr, "null handle");
-    RLC_REQUIRE(agent >= 0 && agent < h->dv.n_agents, "agent %d out of range [0,%d)", agent, h->dv.n_agents);
+    RLC_REQUIRE(agent >= 0 && agent < h->rep.n_agents, "agent %d out of range [0,%d)", agent, h->rep.n_agents);
     return 0;
 }
+int ensure_io(rlc_handle* h, size_t bytes) { return ensure_io_impl(h, bytes); }
 
-float* blob_ptr(rlc_ddpg* h, int which) {
+float* blob_ptr(rlc_handle* h, int which) {
     switch (which) {
         case 0: return h->dv.theta;
         case 1: return h->dv.theta_t;
@@ -84,7 +65,7 @@ float* blob_ptr(rlc_ddpg* h, int which) {
     }
 }
 
-int use_device(const rlc_ddpg* h) {
+int use_device(const rlc_handle* h) {
     RLC_HIP(hipSetDevice(h->device));
     return 0;
 }
@@ -105,56 +86,114 @@ int rlc_device_count(int* out_count) {
     return 0;
 }
 
-int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out) {
-    RLC_REQUIRE(cfg && out, "null argument");
-    RLC_REQUIRE(cfg->n_agents >= 1, "n_agents must be >= 1 (got %d)", cfg->n_agents);
-    RLC_REQUIRE(cfg->state_dim >= 1 && cfg->action_dim >= 1, "state_dim/action_dim must be >= 1");
-    RLC_REQUIRE(cfg->shared_l1_dim >= 1 && cfg->actor_l2_dim >= 1 && cfg->critic_l2_dim >= 1,
-                "layer widths must be >= 1");
-    RLC_REQUIRE(cfg->batch_size >= 1 && cfg->batch_size <= RLC_MAX_BATCH, "batch_size %d outside [1,%d]",
-                cfg->batch_size, RLC_MAX_BATCH);
-    RLC_REQUIRE(cfg->buffer_size >= 1, "buffer_size must be >= 1");
-    RLC_REQUIRE(cfg->state_min && cfg->state_max && cfg->action_min && cfg->action_max, "null bounds array");
-    RLC_REQUIRE(cfg->actor_lr && cfg->critic_lr && cfg->seed, "null per-agent array");
+}  // extern "C"
+
+// ---- shared construction / destruction (C++ linkage; used by the per-algorithm ABI files) -----
+int rlc_h_check_agent(const rlc_handle* h, int agent) { return check_agent(h, agent); }
+int rlc_h_use_device(const rlc_handle* h) { return use_device(h); }
+int rlc_h_ensure_io(rlc_handle* h, size_t bytes) { return ensure_io(h, bytes); }
+
+int rlc_h_ensure_idx(rlc_handle* h, size_t count) {
+    if (count > h->idx_cap) {
+        RLC_HIP(hipStreamSynchronize(h->st));
+        if (h->idx_dev) RLC_HIP(hipFree(h->idx_dev));
+        h->idx_dev = nullptr; h->idx_cap = 0;
+        RLC_HIP(hipMalloc((void**)&h->idx_dev, sizeof(long long) * count * 2));
+        h->idx_cap = count * 2;
+    }
+    return 0;
+}
+
+// device check, stream/events, replay ring + staging minibatch + sampler state (common to every algorithm)
+int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, int A, int B, long long cap,
+                      const uint64_t* seeds) {
+    RLC_REQUIRE(n_agents >= 1, "n_agents must be >= 1 (got %d)", n_agents);
+    RLC_REQUIRE(S >= 1 && A >= 1, "state_dim/action_dim must be >= 1");
+    RLC_REQUIRE(B >= 1 && B <= RLC_MAX_BATCH, "batch_size %d outside [1,%d]", B, RLC_MAX_BATCH);
+    RLC_REQUIRE(cap >= 1, "buffer_size must be >= 1");
+    RLC_REQUIRE(seeds != nullptr, "null per-agent seed array");
     int ndev = 0;
     RLC_HIP(hipGetDeviceCount(&ndev));
-    RLC_REQUIRE(cfg->device >= 0 && cfg->device < ndev, "device %d not present (%d visible)", cfg->device, ndev);
-    RLC_HIP(hipSetDevice(cfg->device));
+    RLC_REQUIRE(device >= 0 && device < ndev, "device %d not present (%d visible)", device, ndev);
+    RLC_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
-    RLC_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    RLC_HIP(hipGetDeviceProperties(&prop, device));
     RLC_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0,
-                "librlcontrol_hip is built for gfx950 (MI355X) only; device %d is %s", cfg->device,
-                prop.gcnArchName);
-
-    rlc_ddpg* h = new rlc_ddpg();
-    memset(&h->dv, 0, sizeof(h->dv));
-    h->device = cfg->device;
+                "librlcontrol_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+    h->algo = algo;
+    h->device = device;
+    h->B = B;
     h->idx_dev = nullptr; h->idx_cap = 0;
     h->io_dev = nullptr; h->io_cap = 0;
     h->io_host = nullptr; h->io_host_cap = 0;
     h->variant = 0;
     h->grad_taps = 0;
-    if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) {
-        rlc_set_error("hipStreamCreate failed");
-        delete h;
-        return 1;
-    }
+    h->st = nullptr;
+    memset(&h->rep, 0, sizeof(h->rep));
+    memset(&h->dv, 0, sizeof(h->dv));
+    memset(&h->sac, 0, sizeof(h->sac));
+    RLC_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);
+    RlcReplayDev& rp = h->rep;
+    rp.S = S; rp.A = A; rp.n_agents = n_agents; rp.cap = cap;
+    const size_t NA = n_agents, c = (size_t)cap;
+    // replay SoA (not zeroed: slots are written before they are read)
+    if (dmalloc(h, &rp.rs, NA * c * S, false) || dmalloc(h, &rp.rs2, NA * c * S, false) ||
+        dmalloc(h, &rp.ra, NA * c * A, false) || dmalloc(h, &rp.rr, NA * c, false) || dmalloc(h, &rp.rg, NA * c, false) ||
+        dmalloc(h, &rp.ring, NA) || dmalloc(h, &rp.gs, NA * RLC_MAX_BATCH * S) || dmalloc(h, &rp.gs2, NA * RLC_MAX_BATCH * S) ||
+        dmalloc(h, &rp.ga, NA * RLC_MAX_BATCH * A) || dmalloc(h, &rp.gr, NA * RLC_MAX_BATCH) ||
+        dmalloc(h, &rp.gg, NA * RLC_MAX_BATCH) || dmalloc(h, &rp.sample_ctr, NA))
+        return 1;
+    unsigned long long* seed_dev;
+    if (dmalloc(h, &seed_dev, NA)) return 1;
+    rp.seed = seed_dev;
+    RLC_HIP(hipMemcpyAsync(seed_dev, seeds, NA * sizeof(unsigned long long), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    h->ring.assign(NA, RlcRingMeta{0, 0});
+    return 0;
+}
+
+void rlc_h_destroy(rlc_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->st) (void)hipStreamSynchronize(h->st);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->idx_dev) (void)hipFree(h->idx_dev);
+    if (h->io_dev) (void)hipFree(h->io_dev);
+    if (h->io_host) (void)hipHostFree(h->io_host);
+    if (h->st) {
+        (void)hipEventDestroy(h->ev0);
+        (void)hipEventDestroy(h->ev1);
+        (void)hipStreamDestroy(h->st);
+    }
+    delete h;
+}
+
+extern "C" {
+
+int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_handle** out) {
+    RLC_REQUIRE(cfg && out, "null argument");
+    RLC_REQUIRE(cfg->shared_l1_dim >= 1 && cfg->actor_l2_dim >= 1 && cfg->critic_l2_dim >= 1,
+                "layer widths must be >= 1");
+    RLC_REQUIRE(cfg->state_min && cfg->state_max && cfg->action_min && cfg->action_max, "null bounds array");
+    RLC_REQUIRE(cfg->actor_lr && cfg->critic_lr, "null per-agent array");
+    rlc_handle* h = new rlc_handle();
+    int rc = rlc_h_init_common(h, RLC_ALGO_DDPG, cfg->device, cfg->n_agents, cfg->state_dim, cfg->action_dim,
+                               cfg->batch_size, cfg->buffer_size, cfg->seed);
+    if (rc) { rlc_h_destroy(h); return rc; }
 
     RlcDev& dv = h->dv;
     dv.d = rlc_make_dims(cfg->state_dim, cfg->action_dim, cfg->shared_l1_dim, cfg->actor_l2_dim,
                          cfg->critic_l2_dim, cfg->batch_size);
+    dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
-    dv.cap = cfg->buffer_size;
     dv.clip_state = cfg->clip_state;
     dv.tau = cfg->tau;
     dv.ou_theta = cfg->ou_theta; dv.ou_mu = cfg->ou_mu; dv.ou_sigma = cfg->ou_sigma;
     const size_t NA = cfg->n_agents, PP = dv.d.Ppad, S = dv.d.S, A = dv.d.A;
-    const size_t cap = (size_t)dv.cap;
 
-    int rc = 0;
-#define TRY(x) do { rc = (x); if (rc) { rlc_ddpg_destroy(h); return rc; } } while (0)
+#define TRY(x) do { rc = (x); if (rc) { rlc_h_destroy(h); return rc; } } while (0)
     TRY(dmalloc(h, &dv.theta, NA * PP));
     TRY(dmalloc(h, &dv.theta_t, NA * PP));
     TRY(dmalloc(h, &dv.m_a, NA * PP));
@@ -163,24 +202,10 @@ int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out) {
     TRY(dmalloc(h, &dv.v_c, NA * PP));
     TRY(dmalloc(h, &dv.pw, NA * 4));
     float *lr_a, *lr_c, *smin, *smax, *amin, *amax;
-    unsigned long long* seed;
-    TRY(dmalloc(h, &lr_a, NA)); TRY(dmalloc(h, &lr_c, NA)); TRY(dmalloc(h, &seed, NA));
+    TRY(dmalloc(h, &lr_a, NA)); TRY(dmalloc(h, &lr_c, NA));
     TRY(dmalloc(h, &smin, S)); TRY(dmalloc(h, &smax, S)); TRY(dmalloc(h, &amin, A)); TRY(dmalloc(h, &amax, A));
-    dv.actor_lr = lr_a; dv.critic_lr = lr_c; dv.seed = seed;
+    dv.actor_lr = lr_a; dv.critic_lr = lr_c;
     dv.smin = smin; dv.smax = smax; dv.amin = amin; dv.amax = amax;
-    // replay SoA (not zeroed: 288 GB parts make this the big allocation; slots are written before read)
-    TRY(dmalloc(h, &dv.rs, NA * cap * S, false));
-    TRY(dmalloc(h, &dv.rs2, NA * cap * S, false));
-    TRY(dmalloc(h, &dv.ra, NA * cap * A, false));
-    TRY(dmalloc(h, &dv.rr, NA * cap, false));
-    TRY(dmalloc(h, &dv.rg, NA * cap, false));
-    TRY(dmalloc(h, &dv.ring, NA));
-    TRY(dmalloc(h, &dv.gs, NA * RLC_MAX_BATCH * S));
-    TRY(dmalloc(h, &dv.gs2, NA * RLC_MAX_BATCH * S));
-    TRY(dmalloc(h, &dv.ga, NA * RLC_MAX_BATCH * A));
-    TRY(dmalloc(h, &dv.gr, NA * RLC_MAX_BATCH));
-    TRY(dmalloc(h, &dv.gg, NA * RLC_MAX_BATCH));
-    TRY(dmalloc(h, &dv.sample_ctr, NA));
     TRY(dmalloc(h, &dv.noise_ctr, NA));
     TRY(dmalloc(h, &dv.ou_state, NA * A));
     TRY(dmalloc(h, &dv.tap_q, NA * RLC_MAX_BATCH));
@@ -204,7 +229,6 @@ int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out) {
     up(dv.ou_state, ou.data(), NA * A * sizeof(float));
     up(lr_a, cfg->actor_lr, NA * sizeof(float));
     up(lr_c, cfg->critic_lr, NA * sizeof(float));
-    up(seed, cfg->seed, NA * sizeof(unsigned long long));
     up(smin, cfg->state_min, S * sizeof(float));
     up(smax, cfg->state_max, S * sizeof(float));
     up(amin, cfg->action_min, A * sizeof(float));
@@ -212,44 +236,37 @@ int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_ddpg** out) {
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     if (e != hipSuccess) {
         rlc_set_error("rlc_ddpg_create: upload failed: %s", hipGetErrorString(e));
-        rlc_ddpg_destroy(h);
+        rlc_h_destroy(h);
         return 1;
     }
-    h->ring.assign(NA, RlcRingMeta{0, 0});
     *out = h;
     return 0;
 }
 
-int rlc_ddpg_destroy(rlc_ddpg* h) {
-    if (!h) return 0;
-    (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->st);
-    for (void* p : h->allocs) (void)hipFree(p);
-    if (h->idx_dev) (void)hipFree(h->idx_dev);
-    if (h->io_dev) (void)hipFree(h->io_dev);
-    if (h->io_host) (void)hipHostFree(h->io_host);
-    (void)hipEventDestroy(h->ev0);
-    (void)hipEventDestroy(h->ev1);
-    (void)hipStreamDestroy(h->st);
-    delete h;
+int rlc_destroy(rlc_handle* h) {
+    rlc_h_destroy(h);
     return 0;
 }
 
-int rlc_ddpg_param_count(const rlc_ddpg* h, int64_t* out_p) {
+#define RLC_NEED_DDPG(h) RLC_REQUIRE((h) && (h)->algo == RLC_ALGO_DDPG, "handle is not a DDPG population")
+
+int rlc_ddpg_param_count(const rlc_handle* h, int64_t* out_p) {
     RLC_REQUIRE(h && out_p, "null argument");
+    RLC_NEED_DDPG(h);
     *out_p = h->dv.d.P;
     return 0;
 }
 
-int rlc_ddpg_sync(rlc_ddpg* h) {
+int rlc_sync(rlc_handle* h) {
     RLC_REQUIRE(h, "null handle");
     if (use_device(h)) return 1;
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
 }
 
-int rlc_ddpg_set_blob(rlc_ddpg* h, int32_t agent, int32_t which, const float* src, int64_t n) {
+int rlc_ddpg_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* src, int64_t n) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     float* base = blob_ptr(h, which);
     RLC_REQUIRE(base && src, "bad blob selector %d or null src", which);
     const RlcDims& d = h->dv.d;
@@ -262,7 +279,7 @@ int rlc_ddpg_set_blob(rlc_ddpg* h, int32_t agent, int32_t which, const float* sr
     return 0;
 }
 
-static int fetch_blob(rlc_ddpg* h, const float* dev_src, float* dst) {
+static int fetch_blob(rlc_handle* h, const float* dev_src, float* dst) {
     const RlcDims& d = h->dv.d;
     std::vector<float> padded(d.Ppad);
     RLC_HIP(hipMemcpyAsync(padded.data(), dev_src, sizeof(float) * d.Ppad, hipMemcpyDeviceToHost, h->st));
@@ -271,32 +288,36 @@ static int fetch_blob(rlc_ddpg* h, const float* dev_src, float* dst) {
     return 0;
 }
 
-int rlc_ddpg_get_blob(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+int rlc_ddpg_get_blob(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     float* base = blob_ptr(h, which);
     RLC_REQUIRE(base && dst, "bad blob selector %d or null dst", which);
     RLC_REQUIRE(n == h->dv.d.P, "blob length %lld != parameter count %d", (long long)n, h->dv.d.P);
     return fetch_blob(h, base + (size_t)agent * h->dv.d.Ppad, dst);
 }
 
-int rlc_ddpg_set_beta_powers(rlc_ddpg* h, int32_t agent, const float* pw4) {
+int rlc_ddpg_set_beta_powers(rlc_handle* h, int32_t agent, const float* pw4) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     RLC_REQUIRE(pw4, "null pw4");
     RLC_HIP(hipMemcpyAsync(h->dv.pw + agent * 4, pw4, 4 * sizeof(float), hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
 }
 
-int rlc_ddpg_get_beta_powers(rlc_ddpg* h, int32_t agent, float* pw4) {
+int rlc_ddpg_get_beta_powers(rlc_handle* h, int32_t agent, float* pw4) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     RLC_REQUIRE(pw4, "null pw4");
     RLC_HIP(hipMemcpyAsync(pw4, h->dv.pw + agent * 4, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
 }
 
-int rlc_ddpg_init_target(rlc_ddpg* h, int32_t agent) {
+int rlc_ddpg_init_target(rlc_handle* h, int32_t agent) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     const size_t off = (size_t)agent * h->dv.d.Ppad;
     RLC_HIP(hipMemcpyAsync(h->dv.theta_t + off, h->dv.theta + off, h->dv.d.Ppad * sizeof(float),
                            hipMemcpyDeviceToDevice, h->st));
@@ -304,11 +325,11 @@ int rlc_ddpg_init_target(rlc_ddpg* h, int32_t agent) {
 }
 
 // ---------------------------------------------------------------------------------------- replay
-int rlc_replay_add(rlc_ddpg* h, int32_t agent, const double* state, const double* action, double reward,
+int rlc_replay_add(rlc_handle* h, int32_t agent, const double* state, const double* action, double reward,
                    const double* next_state, double transition_gamma) {
     if (check_agent(h, agent) || use_device(h)) return 2;
     RLC_REQUIRE(state && action && next_state, "null transition field");
-    const int S = h->dv.d.S, A = h->dv.d.A;
+    const int S = h->rep.S, A = h->rep.A;
     if (2 * S + A > RLC_PUT1_MAX_FLOATS)
         return rlc_replay_add_batch(h, agent, 1, state, action, &reward, next_state, &transition_gamma);
     RlcRingMeta& m = h->ring[agent];
@@ -318,22 +339,22 @@ int rlc_replay_add(rlc_ddpg* h, int32_t agent, const double* state, const double
     t.r = reward;
     t.g = transition_gamma;
     // append on the right; when full the oldest (left) is evicted (custom_collections.py:83-101)
-    t.slot = (m.start + m.size) % h->dv.cap;
-    if (m.size == h->dv.cap) m.start = (m.start + 1) % h->dv.cap;
+    t.slot = (m.start + m.size) % h->rep.cap;
+    if (m.size == h->rep.cap) m.start = (m.start + 1) % h->rep.cap;
     else m.size += 1;
     t.new_start = m.start;
     t.new_size = m.size;
-    return rlc_launch_replay_put1(h->dv, agent, t, h->st);
+    return rlc_launch_replay_put1(h->rep, agent, t, h->st);
 }
 
-int rlc_replay_add_batch(rlc_ddpg* h, int32_t agent, int64_t n, const double* states, const double* actions,
+int rlc_replay_add_batch(rlc_handle* h, int32_t agent, int64_t n, const double* states, const double* actions,
                          const double* rewards, const double* next_states, const double* gammas) {
     if (check_agent(h, agent) || use_device(h)) return 2;
     RLC_REQUIRE(n >= 0, "negative count");
     if (n == 0) return 0;
     RLC_REQUIRE(states && actions && rewards && next_states && gammas, "null transition field");
-    const size_t S = h->dv.d.S, A = h->dv.d.A;
-    const long long cap = h->dv.cap;
+    const size_t S = h->rep.S, A = h->rep.A;
+    const long long cap = h->rep.cap;
     // only the newest `cap` of a longer batch can survive FIFO eviction
     long long skip = n > cap ? n - cap : 0;
     const long long m_eff = n - skip;
@@ -365,34 +386,34 @@ int rlc_replay_add_batch(rlc_ddpg* h, int32_t agent, int64_t n, const double* st
     advance(skip);
     const long long first_slot = (start + size) % cap;   // == start when full
     advance(m_eff);
-    if (rlc_launch_replay_scatter(h->dv, agent, first_slot, m_eff, df, df + 2 * m_eff * S, dd, df + m_eff * S,
+    if (rlc_launch_replay_scatter(h->rep, agent, first_slot, m_eff, df, df + 2 * m_eff * S, dd, df + m_eff * S,
                                   dd + m_eff, h->st))
         return 1;
     m.start = start; m.size = size;
-    if (rlc_launch_set_ring(h->dv, agent, start, size, h->st)) return 1;
+    if (rlc_launch_set_ring(h->rep, agent, start, size, h->st)) return 1;
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
 }
 
-int rlc_replay_fill_all_dev(rlc_ddpg* h, int64_t n, const float* s_dev, const float* a_dev, const double* r_dev,
+int rlc_replay_fill_all_dev(rlc_handle* h, int64_t n, const float* s_dev, const float* a_dev, const double* r_dev,
                             const float* s2_dev, const double* g_dev) {
     RLC_REQUIRE(h, "null handle");
     if (use_device(h)) return 1;
-    RLC_REQUIRE(n >= 1 && n <= h->dv.cap, "fill count %lld outside [1, capacity %lld]", (long long)n, h->dv.cap);
+    RLC_REQUIRE(n >= 1 && n <= h->rep.cap, "fill count %lld outside [1, capacity %lld]", (long long)n, h->rep.cap);
     RLC_REQUIRE(s_dev && a_dev && r_dev && s2_dev && g_dev, "null device array");
-    if (rlc_launch_replay_fill_all(h->dv, n, s_dev, a_dev, r_dev, s2_dev, g_dev, h->st)) return 1;
+    if (rlc_launch_replay_fill_all(h->rep, n, s_dev, a_dev, r_dev, s2_dev, g_dev, h->st)) return 1;
     for (auto& m : h->ring) { m.start = 0; m.size = n; }
     return 0;
 }
 
-int rlc_replay_size(const rlc_ddpg* h, int32_t agent, int64_t* out_size) {
+int rlc_replay_size(const rlc_handle* h, int32_t agent, int64_t* out_size) {
     if (check_agent(h, agent)) return 2;
     RLC_REQUIRE(out_size, "null out_size");
     *out_size = h->ring[agent].size;
     return 0;
 }
 
-int rlc_replay_gather(rlc_ddpg* h, int32_t agent, const int64_t* logical_idx, int32_t k, double* states,
+int rlc_replay_gather(rlc_handle* h, int32_t agent, const int64_t* logical_idx, int32_t k, double* states,
                       double* actions, double* rewards, double* next_states, double* gammas) {
     if (check_agent(h, agent) || use_device(h)) return 2;
     RLC_REQUIRE(k >= 0, "negative k");
@@ -402,7 +423,7 @@ int rlc_replay_gather(rlc_ddpg* h, int32_t agent, const int64_t* logical_idx, in
     for (int i = 0; i < k; i++)
         RLC_REQUIRE(logical_idx[i] >= 0 && logical_idx[i] < size, "RandomAccessQueue index out of range: %lld (size %lld)",
                     (long long)logical_idx[i], size);
-    const size_t S = h->dv.d.S, A = h->dv.d.A;
+    const size_t S = h->rep.S, A = h->rep.A;
     const size_t ibytes = sizeof(long long) * k, dbytes = sizeof(double) * 2 * k, fbytes = sizeof(float) * k * (2 * S + A);
     if (ensure_io(h, ibytes + dbytes + fbytes)) return 1;
     RLC_HIP(hipStreamSynchronize(h->st));
@@ -411,7 +432,7 @@ int rlc_replay_gather(rlc_ddpg* h, int32_t agent, const int64_t* logical_idx, in
     float* df = (float*)(dd + 2 * k);
     memcpy(h->io_host, logical_idx, ibytes);
     RLC_HIP(hipMemcpyAsync(di, h->io_host, ibytes, hipMemcpyHostToDevice, h->st));
-    if (rlc_launch_replay_gather(h->dv, agent, di, k, df, df + 2 * k * S, dd, df + k * S, dd + k, h->st)) return 1;
+    if (rlc_launch_replay_gather(h->rep, agent, di, k, df, df + 2 * k * S, dd, df + k * S, dd + k, h->st)) return 1;
     RLC_HIP(hipMemcpyAsync(h->io_host, h->io_dev, ibytes + dbytes + fbytes, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     const double* hd = (const double*)((const long long*)h->io_host + k);
@@ -422,7 +443,7 @@ int rlc_replay_gather(rlc_ddpg* h, int32_t agent, const int64_t* logical_idx, in
     return 0;
 }
 
-int rlc_replay_sample_indices(rlc_ddpg* h, int32_t agent, int32_t k, int64_t* out_idx) {
+int rlc_replay_sample_indices(rlc_handle* h, int32_t agent, int32_t k, int64_t* out_idx) {
     if (check_agent(h, agent) || use_device(h)) return 2;
     const long long size = h->ring[agent].size;
     // utils/custom_collections.py:110-111
@@ -431,15 +452,15 @@ int rlc_replay_sample_indices(rlc_ddpg* h, int32_t agent, int32_t k, int64_t* ou
     if (k == 0) return 0;
     RLC_REQUIRE(out_idx, "null out_idx");
     if (ensure_io(h, sizeof(long long) * k)) return 1;
-    if (rlc_launch_sample_indices(h->dv, agent, k, (long long*)h->io_dev, h->st)) return 1;
+    if (rlc_launch_sample_indices(h->rep, agent, k, (long long*)h->io_dev, h->st)) return 1;
     RLC_HIP(hipMemcpyAsync(out_idx, h->io_dev, sizeof(long long) * k, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
 }
 
 // ---------------------------------------------------------------------------------------- acting
-static int act_common(rlc_ddpg* h, int first_agent, int n, const double* states, float* out_actions, int explore) {
-    RLC_REQUIRE(h, "null handle");
+static int act_common(rlc_handle* h, int first_agent, int n, const double* states, float* out_actions, int explore) {
+    RLC_NEED_DDPG(h);
     if (use_device(h)) return 1;
     RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->dv.n_agents, "agent range [%d,%d) invalid",
                 first_agent, first_agent + n);
@@ -459,23 +480,24 @@ static int act_common(rlc_ddpg* h, int first_agent, int n, const double* states,
     return 0;
 }
 
-int rlc_ddpg_act(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions) {
+int rlc_ddpg_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, float* out_actions) {
     return act_common(h, first_agent, n, states, out_actions, 0);
 }
 
-int rlc_ddpg_act_explore(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions) {
+int rlc_ddpg_act_explore(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, float* out_actions) {
     return act_common(h, first_agent, n, states, out_actions, 1);
 }
 
-int rlc_ddpg_reset_noise(rlc_ddpg* h, int32_t first_agent, int32_t n) {
-    RLC_REQUIRE(h, "null handle");
+int rlc_ddpg_reset_noise(rlc_handle* h, int32_t first_agent, int32_t n) {
+    RLC_NEED_DDPG(h);
     if (use_device(h)) return 1;
     RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->dv.n_agents, "agent range invalid");
     return rlc_launch_reset_noise(h->dv, first_agent, n, h->st);
 }
 
-int rlc_ddpg_qval(rlc_ddpg* h, int32_t agent, int32_t n, const double* states, const double* actions, float* out_q) {
+int rlc_ddpg_qval(rlc_handle* h, int32_t agent, int32_t n, const double* states, const double* actions, float* out_q) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     RLC_REQUIRE(n >= 1 && states && actions && out_q, "bad arguments");
     const size_t S = h->dv.d.S, A = h->dv.d.A;
     const size_t in_b = sizeof(float) * n * (S + A), out_b = sizeof(float) * n;
@@ -493,12 +515,12 @@ int rlc_ddpg_qval(rlc_ddpg* h, int32_t agent, int32_t n, const double* states, c
 }
 
 // -------------------------------------------------------------------------------------- learning
-static int pick_variant(const rlc_ddpg* h) {
+static int pick_variant(const rlc_handle* h) {
     if (h->variant == 1 || h->variant == 2) return h->variant;
     return rlc_mfma_supported(h->dv.d) ? 2 : 1;
 }
 
-static int launch_update(rlc_ddpg* h, int first, int n, int n_updates, int source, const long long* idx_dev) {
+static int launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev) {
     const int v = pick_variant(h);
     if (v == 2) {
         RLC_REQUIRE(rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
@@ -507,8 +529,8 @@ static int launch_update(rlc_ddpg* h, int first, int n, int n_updates, int sourc
     return rlc_launch_ddpg_update_generic(h->dv, first, n, n_updates, source, idx_dev, h->grad_taps, h->st);
 }
 
-int rlc_ddpg_update(rlc_ddpg* h, int32_t n_updates, const int64_t* host_indices) {
-    RLC_REQUIRE(h, "null handle");
+int rlc_ddpg_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices) {
+    RLC_NEED_DDPG(h);
     if (use_device(h)) return 1;
     RLC_REQUIRE(n_updates >= 0, "negative n_updates");
     if (n_updates == 0) return 0;
@@ -526,22 +548,17 @@ int rlc_ddpg_update(rlc_ddpg* h, int32_t n_updates, const int64_t* host_indices)
                 RLC_REQUIRE(p[i] >= 0 && p[i] < size, "agent %d: sample index %lld out of range (size %lld)", a,
                             (long long)p[i], size);
         }
-        if (count > h->idx_cap) {
-            RLC_HIP(hipStreamSynchronize(h->st));
-            if (h->idx_dev) RLC_HIP(hipFree(h->idx_dev));
-            h->idx_dev = nullptr; h->idx_cap = 0;
-            RLC_HIP(hipMalloc((void**)&h->idx_dev, sizeof(long long) * count * 2));
-            h->idx_cap = count * 2;
-        }
+        if (rlc_h_ensure_idx(h, count)) return 1;
         RLC_HIP(hipMemcpyAsync(h->idx_dev, host_indices, sizeof(long long) * count, hipMemcpyHostToDevice, h->st));
         source = RLC_SRC_REPLAY_HOST_INDICES;
     }
     return launch_update(h, 0, NA, n_updates, source, h->idx_dev);
 }
 
-int rlc_ddpg_update_batch(rlc_ddpg* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+int rlc_ddpg_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const double* states, const double* actions,
                           const double* next_states, const double* rewards, const double* gammas) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     RLC_REQUIRE(batch == h->dv.d.B, "minibatch has %d rows; the handle was created for batch_size %d", batch, h->dv.d.B);
     RLC_REQUIRE(states && actions && next_states && rewards && gammas, "null minibatch array");
     const size_t S = h->dv.d.S, A = h->dv.d.A, B = batch;
@@ -554,30 +571,32 @@ int rlc_ddpg_update_batch(rlc_ddpg* h, int32_t agent, int32_t batch, const doubl
     for (size_t i = 0; i < B * S; i++) { hf[i] = (float)states[i]; hf[B * S + i] = (float)next_states[i]; }
     for (size_t i = 0; i < B * A; i++) hf[2 * B * S + i] = (float)actions[i];
     const size_t slot = (size_t)agent * RLC_MAX_BATCH;
-    RLC_HIP(hipMemcpyAsync(h->dv.gr + slot, hd, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
-    RLC_HIP(hipMemcpyAsync(h->dv.gg + slot, hd + B, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
-    RLC_HIP(hipMemcpyAsync(h->dv.gs + slot * S, hf, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
-    RLC_HIP(hipMemcpyAsync(h->dv.gs2 + slot * S, hf + B * S, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
-    RLC_HIP(hipMemcpyAsync(h->dv.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.gr + slot, hd, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.gg + slot, hd + B, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.gs + slot * S, hf, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.gs2 + slot * S, hf + B * S, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
     return launch_update(h, agent, 1, 1, RLC_SRC_STAGING, nullptr);
 }
 
-int rlc_ddpg_set_kernel(rlc_ddpg* h, int32_t variant) {
+int rlc_ddpg_set_kernel(rlc_handle* h, int32_t variant) {
     RLC_REQUIRE(h, "null handle");
+    RLC_NEED_DDPG(h);
     RLC_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (auto), 1 (generic) or 2 (mfma)");
     RLC_REQUIRE(variant != 2 || rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
     h->variant = variant;
     return 0;
 }
 
-int rlc_ddpg_get_kernel(const rlc_ddpg* h, int32_t* variant_in_use) {
+int rlc_ddpg_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {
     RLC_REQUIRE(h && variant_in_use, "null argument");
     *variant_in_use = pick_variant(h);
     return 0;
 }
 
-int rlc_ddpg_last_tap(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+int rlc_ddpg_last_tap(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
     if (check_agent(h, agent) || use_device(h)) return 2;
+    RLC_NEED_DDPG(h);
     RLC_REQUIRE(dst, "null dst");
     const int B = h->dv.d.B, A = h->dv.d.A, P = h->dv.d.P;
     const float* src = nullptr;
@@ -599,8 +618,9 @@ int rlc_ddpg_last_tap(rlc_ddpg* h, int32_t agent, int32_t which, float* dst, int
     return 0;
 }
 
-int rlc_ddpg_enable_grad_taps(rlc_ddpg* h, int32_t on) {
+int rlc_ddpg_enable_grad_taps(rlc_handle* h, int32_t on) {
     RLC_REQUIRE(h, "null handle");
+    RLC_NEED_DDPG(h);
     if (use_device(h)) return 1;
     if (on && !h->dv.tap_gc) {
         const size_t n = (size_t)h->dv.n_agents * h->dv.d.Ppad;
@@ -611,14 +631,14 @@ int rlc_ddpg_enable_grad_taps(rlc_ddpg* h, int32_t on) {
     return 0;
 }
 
-int rlc_timer_begin(rlc_ddpg* h) {
+int rlc_timer_begin(rlc_handle* h) {
     RLC_REQUIRE(h, "null handle");
     if (use_device(h)) return 1;
     RLC_HIP(hipEventRecord(h->ev0, h->st));
     return 0;
 }
 
-int rlc_timer_end(rlc_ddpg* h, float* out_ms) {
+int rlc_timer_end(rlc_handle* h, float* out_ms) {
     RLC_REQUIRE(h && out_ms, "null argument");
     if (use_device(h)) return 1;
     RLC_HIP(hipEventRecord(h->ev1, h->st));

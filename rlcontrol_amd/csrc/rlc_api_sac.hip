@@ -1,0 +1,270 @@
+// rlc_api_sac.hip -- C ABI of the SoftActorCritic population (declared in include/rlcontrol_hip.h).
+#include <string.h>
+
+#include "rlc_handle.h"
+
+#define RLC_NEED_SAC(h) RLC_REQUIRE((h) && (h)->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population")
+
+namespace {
+
+float* sac_blob(rlc_handle* h, int which) {
+    switch (which) {
+        case 0: return h->sac.theta;
+        case 1: return h->sac.theta_t;
+        case 2: return h->sac.m;
+        case 3: return h->sac.v;
+        default: return nullptr;
+    }
+}
+
+int sac_fetch_blob(rlc_handle* h, const float* dev_src, float* dst) {
+    const RlcSacDims& d = h->sac.d;
+    std::vector<float> padded(d.Ppad);
+    RLC_HIP(hipMemcpyAsync(padded.data(), dev_src, sizeof(float) * d.Ppad, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    for (int i = 0; i < RLC_SAC_NSEG; i++)
+        memcpy(dst + d.seg_compact[i], &padded[d.seg_dev[i]], sizeof(float) * d.seg_len[i]);
+    return 0;
+}
+
+// host eps [count] -> device buffer behind the index upload area; returns device pointer (or null if eps null)
+int upload_eps(rlc_handle* h, const float* eps, size_t count, const float** out_dev, size_t idx_count) {
+    *out_dev = nullptr;
+    if (!eps) return 0;
+    // layout of idx_dev: [idx_count long long][count floats]
+    const size_t need_ll = idx_count + (count * sizeof(float) + 7) / 8;
+    if (rlc_h_ensure_idx(h, need_ll)) return 1;
+    float* dst = (float*)(h->idx_dev + idx_count);
+    RLC_HIP(hipMemcpyAsync(dst, eps, sizeof(float) * count, hipMemcpyHostToDevice, h->st));
+    *out_dev = dst;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rlc_sac_create(const rlc_sac_config* cfg, rlc_handle** out) {
+    RLC_REQUIRE(cfg && out, "null argument");
+    RLC_REQUIRE(cfg->actor_l1_dim >= 1 && cfg->actor_l2_dim >= 1 && cfg->critic_l1_dim >= 1 && cfg->critic_l2_dim >= 1,
+                "layer widths must be >= 1");
+    RLC_REQUIRE(cfg->pi_lr && cfg->qf_vf_lr && cfg->entropy_scale, "null per-agent array");
+    rlc_handle* h = new rlc_handle();
+    int rc = rlc_h_init_common(h, RLC_ALGO_SAC, cfg->device, cfg->n_agents, cfg->state_dim, cfg->action_dim,
+                               cfg->batch_size, cfg->buffer_size, cfg->seed);
+    if (rc) { rlc_h_destroy(h); return rc; }
+    RlcSacDev& dv = h->sac;
+    dv.d = rlc_sac_make_dims(cfg->state_dim, cfg->action_dim, cfg->actor_l1_dim, cfg->actor_l2_dim,
+                             cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size);
+    dv.rep = h->rep;
+    dv.n_agents = cfg->n_agents;
+    dv.clip_state = cfg->clip_state;
+    dv.tau = cfg->tau;
+    dv.smin0 = cfg->state_min0; dv.smax0 = cfg->state_max0; dv.amax0 = cfg->action_max0;
+    const size_t NA = cfg->n_agents, PP = dv.d.Ppad;
+#define TRY(x) do { rc = (x); if (rc) { rlc_h_destroy(h); return rc; } } while (0)
+    TRY(rlc_h_malloc(h, &dv.theta, NA * PP));
+    TRY(rlc_h_malloc(h, &dv.theta_t, NA * PP));
+    TRY(rlc_h_malloc(h, &dv.m, NA * PP));
+    TRY(rlc_h_malloc(h, &dv.v, NA * PP));
+    TRY(rlc_h_malloc(h, &dv.pw, NA * 4));
+    float *lp, *lq, *al;
+    TRY(rlc_h_malloc(h, &lp, NA)); TRY(rlc_h_malloc(h, &lq, NA)); TRY(rlc_h_malloc(h, &al, NA));
+    dv.pi_lr = lp; dv.qv_lr = lq; dv.alpha = al;
+    TRY(rlc_h_malloc(h, &dv.noise_ctr, NA));
+    TRY(rlc_h_malloc(h, &dv.tap_q, NA * RLC_MAX_BATCH));
+    TRY(rlc_h_malloc(h, &dv.tap_v, NA * RLC_MAX_BATCH));
+    TRY(rlc_h_malloc(h, &dv.tap_logp, NA * RLC_MAX_BATCH));
+    TRY(rlc_h_malloc(h, &dv.tap_qpi, NA * RLC_MAX_BATCH));
+    TRY(rlc_h_malloc(h, &dv.tap_loss, NA * 4));
+    dv.tap_g = nullptr;
+    dv.scratch_stride = (long long)((rlc_sac_scratch_floats(dv.d) + 63) & ~(size_t)63);
+    TRY(rlc_h_malloc(h, &dv.scratch, NA * (size_t)dv.scratch_stride, false));
+#undef TRY
+    std::vector<float> pw(NA * 4);
+    for (size_t i = 0; i < NA; i++) { pw[4 * i] = 0.9f; pw[4 * i + 1] = 0.999f; pw[4 * i + 2] = 0.9f; pw[4 * i + 3] = 0.999f; }
+    hipError_t e = hipMemcpyAsync(dv.pw, pw.data(), NA * 4 * sizeof(float), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(lp, cfg->pi_lr, NA * sizeof(float), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(lq, cfg->qf_vf_lr, NA * sizeof(float), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(al, cfg->entropy_scale, NA * sizeof(float), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->st);
+    if (e != hipSuccess) {
+        rlc_set_error("rlc_sac_create: upload failed: %s", hipGetErrorString(e));
+        rlc_h_destroy(h);
+        return 1;
+    }
+    *out = h;
+    return 0;
+}
+
+int rlc_sac_param_count(const rlc_handle* h, int64_t* out_p) {
+    RLC_REQUIRE(h && out_p, "null argument");
+    RLC_NEED_SAC(h);
+    *out_p = h->sac.d.P;
+    return 0;
+}
+
+int rlc_sac_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* src, int64_t n) {
+    if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
+    RLC_NEED_SAC(h);
+    float* base = sac_blob(h, which);
+    RLC_REQUIRE(base && src, "bad blob selector %d or null src", which);
+    const RlcSacDims& d = h->sac.d;
+    RLC_REQUIRE(n == d.P, "blob length %lld != parameter count %d", (long long)n, d.P);
+    std::vector<float> padded(d.Ppad, 0.0f);
+    for (int i = 0; i < RLC_SAC_NSEG; i++)
+        memcpy(&padded[d.seg_dev[i]], src + d.seg_compact[i], sizeof(float) * d.seg_len[i]);
+    RLC_HIP(hipMemcpyAsync(base + (size_t)agent * d.Ppad, padded.data(), sizeof(float) * d.Ppad, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_sac_get_blob(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+    if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
+    RLC_NEED_SAC(h);
+    float* base = sac_blob(h, which);
+    RLC_REQUIRE(base && dst, "bad blob selector %d or null dst", which);
+    RLC_REQUIRE(n == h->sac.d.P, "blob length %lld != parameter count %d", (long long)n, h->sac.d.P);
+    return sac_fetch_blob(h, base + (size_t)agent * h->sac.d.Ppad, dst);
+}
+
+int rlc_sac_set_beta_powers(rlc_handle* h, int32_t agent, const float* pw4) {
+    if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
+    RLC_NEED_SAC(h);
+    RLC_REQUIRE(pw4, "null pw4");
+    RLC_HIP(hipMemcpyAsync(h->sac.pw + agent * 4, pw4, 4 * sizeof(float), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_sac_get_beta_powers(rlc_handle* h, int32_t agent, float* pw4) {
+    if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
+    RLC_NEED_SAC(h);
+    RLC_REQUIRE(pw4, "null pw4");
+    RLC_HIP(hipMemcpyAsync(pw4, h->sac.pw + agent * 4, 4 * sizeof(float), hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_sac_init_target(rlc_handle* h, int32_t agent) {
+    if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
+    RLC_NEED_SAC(h);
+    const size_t off = (size_t)agent * h->sac.d.Ppad;
+    RLC_HIP(hipMemcpyAsync(h->sac.theta_t + off, h->sac.theta + off, h->sac.d.Ppad * sizeof(float),
+                           hipMemcpyDeviceToDevice, h->st));
+    return 0;
+}
+
+int rlc_sac_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
+                float* out_actions) {
+    RLC_NEED_SAC(h);
+    if (rlc_h_use_device(h)) return 1;
+    RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->sac.n_agents, "agent range [%d,%d) invalid",
+                first_agent, first_agent + n);
+    RLC_REQUIRE(states && out_actions, "null array");
+    const size_t S = h->sac.d.S, A = h->sac.d.A;
+    const size_t in_f = n * S, eps_f = (sample && eps) ? n * A : 0, out_f = n * A;
+    if (rlc_h_ensure_io(h, sizeof(float) * (in_f + eps_f + out_f))) return 1;
+    float* hin = (float*)h->io_host;
+    for (size_t i = 0; i < in_f; i++) hin[i] = (float)states[i];
+    for (size_t i = 0; i < eps_f; i++) hin[in_f + i] = eps[i];
+    RLC_HIP(hipMemcpyAsync(h->io_dev, hin, sizeof(float) * (in_f + eps_f), hipMemcpyHostToDevice, h->st));
+    float* dout = h->io_dev + in_f + eps_f;
+    if (rlc_launch_sac_act(h->sac, first_agent, n, h->io_dev, eps_f ? h->io_dev + in_f : nullptr, sample ? 1 : 0, dout,
+                           h->st))
+        return 1;
+    RLC_HIP(hipMemcpyAsync(hin + in_f + eps_f, dout, sizeof(float) * out_f, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    memcpy(out_actions, hin + in_f + eps_f, sizeof(float) * out_f);
+    return 0;
+}
+
+int rlc_sac_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps) {
+    RLC_NEED_SAC(h);
+    if (rlc_h_use_device(h)) return 1;
+    RLC_REQUIRE(n_updates >= 0, "negative n_updates");
+    if (n_updates == 0) return 0;
+    const int B = h->B, NA = h->sac.n_agents, A = h->sac.d.A;
+    for (int a = 0; a < NA; a++)   // utils/replaybuffer.py:34
+        RLC_REQUIRE(h->ring[a].size >= B, "agent %d: replay holds %lld transitions < batch_size %d", a, h->ring[a].size, B);
+    int source = RLC_SRC_REPLAY_DEVICE_SAMPLER;
+    const size_t count = (size_t)NA * n_updates * B;
+    const size_t idx_count = host_indices ? count : 0;
+    const float* eps_dev = nullptr;
+    if (host_indices) {
+        for (int a = 0; a < NA; a++) {
+            const long long size = h->ring[a].size;
+            const int64_t* p = host_indices + (size_t)a * n_updates * B;
+            for (size_t i = 0; i < (size_t)n_updates * B; i++)
+                RLC_REQUIRE(p[i] >= 0 && p[i] < size, "agent %d: sample index %lld out of range (size %lld)", a,
+                            (long long)p[i], size);
+        }
+        if (rlc_h_ensure_idx(h, count + (eps ? (count * A * sizeof(float) + 7) / 8 : 0))) return 1;
+        RLC_HIP(hipMemcpyAsync(h->idx_dev, host_indices, sizeof(long long) * count, hipMemcpyHostToDevice, h->st));
+        source = RLC_SRC_REPLAY_HOST_INDICES;
+    }
+    if (upload_eps(h, eps, count * A, &eps_dev, idx_count)) return 1;
+    return rlc_launch_sac_update(h->sac, 0, NA, n_updates, source, h->idx_dev, eps_dev, h->grad_taps, h->st);
+}
+
+int rlc_sac_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+                         const double* next_states, const double* rewards, const double* gammas, const float* eps) {
+    if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
+    RLC_NEED_SAC(h);
+    RLC_REQUIRE(batch == h->B, "minibatch has %d rows; the handle was created for batch_size %d", batch, h->B);
+    RLC_REQUIRE(states && actions && next_states && rewards && gammas, "null minibatch array");
+    const size_t S = h->sac.d.S, A = h->sac.d.A, B = batch;
+    const size_t fbytes = sizeof(float) * B * (2 * S + A), dbytes = sizeof(double) * 2 * B;
+    if (rlc_h_ensure_io(h, fbytes + dbytes)) return 1;
+    RLC_HIP(hipStreamSynchronize(h->st));
+    double* hd = (double*)h->io_host;
+    float* hf = (float*)(hd + 2 * B);
+    for (size_t i = 0; i < B; i++) { hd[i] = rewards[i]; hd[B + i] = gammas[i]; }
+    for (size_t i = 0; i < B * S; i++) { hf[i] = (float)states[i]; hf[B * S + i] = (float)next_states[i]; }
+    for (size_t i = 0; i < B * A; i++) hf[2 * B * S + i] = (float)actions[i];
+    const size_t slot = (size_t)agent * RLC_MAX_BATCH;
+    RLC_HIP(hipMemcpyAsync(h->rep.gr + slot, hd, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.gg + slot, hd + B, sizeof(double) * B, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.gs + slot * S, hf, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.gs2 + slot * S, hf + B * S, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipMemcpyAsync(h->rep.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
+    const float* eps_dev = nullptr;
+    if (upload_eps(h, eps, B * A, &eps_dev, 0)) return 1;
+    return rlc_launch_sac_update(h->sac, agent, 1, 1, RLC_SRC_STAGING, nullptr, eps_dev, h->grad_taps, h->st);
+}
+
+int rlc_sac_enable_grad_taps(rlc_handle* h, int32_t on) {
+    RLC_NEED_SAC(h);
+    if (rlc_h_use_device(h)) return 1;
+    if (on && !h->sac.tap_g) {
+        if (rlc_h_malloc(h, &h->sac.tap_g, (size_t)h->sac.n_agents * h->sac.d.Ppad)) return 1;
+    }
+    h->grad_taps = on ? 1 : 0;
+    return 0;
+}
+
+int rlc_sac_last_tap(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+    if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
+    RLC_NEED_SAC(h);
+    RLC_REQUIRE(dst, "null dst");
+    const int B = h->B, P = h->sac.d.P;
+    const float* src = nullptr;
+    long long want = 0;
+    switch (which) {
+        case 0: src = h->sac.tap_q + (size_t)agent * RLC_MAX_BATCH; want = B; break;
+        case 1: src = h->sac.tap_v + (size_t)agent * RLC_MAX_BATCH; want = B; break;
+        case 2: src = h->sac.tap_logp + (size_t)agent * RLC_MAX_BATCH; want = B; break;
+        case 3: src = h->sac.tap_qpi + (size_t)agent * RLC_MAX_BATCH; want = B; break;
+        case 4: src = h->sac.tap_loss + (size_t)agent * 4; want = 3; break;
+        case 5: src = h->sac.tap_g ? h->sac.tap_g + (size_t)agent * h->sac.d.Ppad : nullptr; want = P; break;
+        default: break;
+    }
+    RLC_REQUIRE(src, "tap %d not available (gradient taps need rlc_sac_enable_grad_taps)", which);
+    RLC_REQUIRE(n == want, "tap %d holds %lld floats, caller asked for %lld", which, want, (long long)n);
+    if (which == 5) return sac_fetch_blob(h, src, dst);
+    RLC_HIP(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+}  // extern "C"

@@ -75,11 +75,22 @@ struct RlcRingMeta {
     long long size;    // number stored (<= cap)
 };
 
-// Everything a kernel needs; passed by value as a kernel argument (all pointers are device memory).
+// Device view of the replay of a population (any algorithm): SoA ring per agent + a staging minibatch.
+struct RlcReplayDev {
+    int S, A, n_agents;
+    long long cap;               // capacity per agent
+    float* rs; float* ra; double* rr; float* rs2; double* rg;     // [n_agents][cap][*]
+    RlcRingMeta* ring;           // [n_agents]
+    float* gs; float* ga; double* gr; float* gs2; double* gg;     // staging minibatch [n_agents][RLC_MAX_BATCH][*]
+    const unsigned long long* seed;      // [n_agents] Philox keys
+    unsigned long long* sample_ctr;      // [n_agents] sampler invocations so far
+};
+
+// Everything the DDPG kernels need; passed by value as a kernel argument (all pointers are device memory).
 struct RlcDev {
     RlcDims d;
+    RlcReplayDev rep;
     int n_agents;
-    long long cap;               // replay capacity per agent
     int clip_state;
     float tau;
     float ou_theta, ou_mu, ou_sigma;
@@ -88,14 +99,6 @@ struct RlcDev {
     float* pw;                   // [n_agents][4] beta powers {a1,a2,c1,c2}
     const float *actor_lr, *critic_lr;   // [n_agents]
     const float *smin, *smax, *amin, *amax;
-    // replay SoA: [n_agents][cap][*]
-    float* rs; float* ra; double* rr; float* rs2; double* rg;
-    RlcRingMeta* ring;           // [n_agents]
-    // staging minibatch (update_batch): [n_agents][RLC_MAX_BATCH][*]
-    float* gs; float* ga; double* gr; float* gs2; double* gg;
-    // device RNG
-    const unsigned long long* seed;      // [n_agents] Philox keys
-    unsigned long long* sample_ctr;      // [n_agents] sampler invocations so far
     unsigned long long* noise_ctr;       // [n_agents] OU draws so far
     float* ou_state;                     // [n_agents][A]
     // taps of the last update: [n_agents][B], [B], [B*A], [B*A]; grads [n_agents][Ppad] (optional)
@@ -127,13 +130,13 @@ int rlc_launch_qval(const RlcDev& dv, int agent, int n, const float* states_dev,
 int rlc_launch_reset_noise(const RlcDev& dv, int first_agent, int n, hipStream_t st);
 size_t rlc_generic_scratch_floats(const RlcDims& d);
 // replay
-int rlc_launch_replay_scatter(const RlcDev& dv, int agent, long long first_slot, long long n, const float* s,
+int rlc_launch_replay_scatter(const RlcReplayDev& rp, int agent, long long first_slot, long long n, const float* s,
                               const float* a, const double* r, const float* s2, const double* g, hipStream_t st);
-int rlc_launch_replay_fill_all(const RlcDev& dv, long long n, const float* s, const float* a, const double* r,
+int rlc_launch_replay_fill_all(const RlcReplayDev& rp, long long n, const float* s, const float* a, const double* r,
                                const float* s2, const double* g, hipStream_t st);
-int rlc_launch_replay_gather(const RlcDev& dv, int agent, const long long* logical_idx_dev, int k, float* s,
+int rlc_launch_replay_gather(const RlcReplayDev& rp, int agent, const long long* logical_idx_dev, int k, float* s,
                              float* a, double* r, float* s2, double* g, hipStream_t st);
-int rlc_launch_sample_indices(const RlcDev& dv, int agent, int k, long long* out_idx_dev, hipStream_t st);
+int rlc_launch_sample_indices(const RlcReplayDev& rp, int agent, int k, long long* out_idx_dev, hipStream_t st);
 // single transition passed by value (no staging copy): ReplayBuffer.add for one env step
 #define RLC_PUT1_MAX_FLOATS 56
 struct RlcPut1 {
@@ -141,8 +144,8 @@ struct RlcPut1 {
     double r, g;
     long long slot, new_start, new_size;
 };
-int rlc_launch_replay_put1(const RlcDev& dv, int agent, const RlcPut1& t, hipStream_t st);
-int rlc_launch_set_ring(const RlcDev& dv, int agent, long long start, long long size, hipStream_t st);
+int rlc_launch_replay_put1(const RlcReplayDev& rp, int agent, const RlcPut1& t, hipStream_t st);
+int rlc_launch_set_ring(const RlcReplayDev& rp, int agent, long long start, long long size, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // device-side helpers

@@ -1,0 +1,47 @@
+// rlc_handle.h -- the one opaque handle type behind rlc_ddpg / rlc_sac / rlc_naf (include/rlcontrol_hip.h):
+// a population of independent agents of ONE algorithm on one GPU.  The replay ring, the staging buffers,
+// the stream and the timer are common; the networks and optimizer state are per algorithm.
+#pragma once
+#include "rlc_common.h"
+#include "sac_common.h"
+
+enum RlcAlgo { RLC_ALGO_DDPG = 1, RLC_ALGO_SAC = 2, RLC_ALGO_NAF = 3 };
+
+struct rlc_handle {
+    int algo;
+    int device;
+    int B;                               // batch_size
+    hipStream_t st;
+    hipEvent_t ev0, ev1;
+    RlcReplayDev rep;                    // device view of the replay (also copied into the per-algorithm views)
+    std::vector<RlcRingMeta> ring;       // host mirror of the ring metadata
+    std::vector<void*> allocs;           // every hipMalloc of this handle
+    long long* idx_dev; size_t idx_cap;  // host-index upload buffer
+    float* io_dev; size_t io_cap;        // act / qval / gather staging (device, bytes)
+    void* io_host; size_t io_host_cap;   // pinned host staging (bytes)
+    // ---- DDPG
+    RlcDev dv;
+    int variant;                         // requested kernel: 0 auto, 1 generic, 2 mfma
+    int grad_taps;
+    // ---- SAC
+    RlcSacDev sac;
+};
+
+// shared helpers (rlc_api.hip)
+int rlc_h_check_agent(const rlc_handle* h, int agent);
+int rlc_h_use_device(const rlc_handle* h);
+int rlc_h_ensure_io(rlc_handle* h, size_t bytes);
+int rlc_h_ensure_idx(rlc_handle* h, size_t count);
+int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, int A, int B, long long cap,
+                      const uint64_t* seeds);
+void rlc_h_destroy(rlc_handle* h);
+template <typename T>
+int rlc_h_malloc(rlc_handle* h, T** out, size_t count, bool zero = true) {
+    void* p = nullptr;
+    const size_t bytes = (count ? count : 1) * sizeof(T);
+    RLC_HIP(hipMalloc(&p, bytes));
+    if (zero) RLC_HIP(hipMemsetAsync(p, 0, bytes, h->st));
+    h->allocs.push_back(p);
+    *out = (T*)p;
+    return 0;
+}

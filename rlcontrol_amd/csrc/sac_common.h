@@ -1,0 +1,61 @@
+// sac_common.h -- geometry and device view of the SoftActorCritic (SAC-v1) population.
+// Blob = variable creation order under 'main' (agents/network/sac_network.py:152-172):
+//   pi: W1[S,L1a] b1 W2[L1a,L2a] b2 Wm[L2a,A] bm Ws[L2a,A] bs | qf: W1[S,L1c] b1 W2[L1c+A,L2c] b2 W3[L2c] b3 |
+//   vf: W1[S,L1c] b1 W2[L1c,L2c] b2 W3[L2c] b3
+// Device layout pads every tensor to 64 floats (same scheme as RlcDims); the ABI blob is compact.
+#pragma once
+#include "rlc_common.h"
+
+#define RLC_SAC_NSEG 20
+
+struct RlcSacDims {
+    int S, A, L1A, L2A, L1C, L2C, B;
+    int pW1, pb1, pW2, pb2, pWm, pbm, pWs, pbs, qW1, qb1, qW2, qb2, qW3, qb3, vW1, vb1, vW2, vb2, vW3, vb3;
+    int Ppi_dev;     // device offset where the qf block starts (pi optimizer owns [0, Ppi_dev))
+    int P, Pdev, Ppad;
+    int seg_len[RLC_SAC_NSEG], seg_compact[RLC_SAC_NSEG], seg_dev[RLC_SAC_NSEG];
+};
+
+inline RlcSacDims rlc_sac_make_dims(int S, int A, int L1A, int L2A, int L1C, int L2C, int B) {
+    RlcSacDims d;
+    d.S = S; d.A = A; d.L1A = L1A; d.L2A = L2A; d.L1C = L1C; d.L2C = L2C; d.B = B;
+    const int len[RLC_SAC_NSEG] = {S * L1A, L1A, L1A * L2A, L2A, L2A * A, A, L2A * A, A,
+                                   S * L1C, L1C, (L1C + A) * L2C, L2C, L2C, 1,
+                                   S * L1C, L1C, L1C * L2C, L2C, L2C, 1};
+    int pc = 0, pd = 0;
+    for (int i = 0; i < RLC_SAC_NSEG; i++) {
+        d.seg_len[i] = len[i]; d.seg_compact[i] = pc; d.seg_dev[i] = pd;
+        pc += len[i];
+        pd += (len[i] + 63) & ~63;
+    }
+    int* o[RLC_SAC_NSEG] = {&d.pW1, &d.pb1, &d.pW2, &d.pb2, &d.pWm, &d.pbm, &d.pWs, &d.pbs, &d.qW1, &d.qb1,
+                            &d.qW2, &d.qb2, &d.qW3, &d.qb3, &d.vW1, &d.vb1, &d.vW2, &d.vb2, &d.vW3, &d.vb3};
+    for (int i = 0; i < RLC_SAC_NSEG; i++) *o[i] = d.seg_dev[i];
+    d.Ppi_dev = d.qW1;
+    d.P = pc; d.Pdev = pd; d.Ppad = pd;
+    return d;
+}
+
+struct RlcSacDev {
+    RlcSacDims d;
+    RlcReplayDev rep;
+    int n_agents;
+    int clip_state;
+    float tau, smin0, smax0, amax0;
+    float *theta, *theta_t, *m, *v;      // [n_agents][Ppad]; pi-Adam owns the pi block, value-Adam the rest
+    float* pw;                           // [n_agents][4] {pi b1^t, pi b2^t, value b1^t, value b2^t}
+    const float *pi_lr, *qv_lr, *alpha;  // [n_agents]
+    unsigned long long* noise_ctr;       // [n_agents] Philox draws of eps so far
+    // taps of the last update [n_agents][RLC_MAX_BATCH]: q, v, logp, q_pi; losses [n_agents][4]; grads [n_agents][Ppad]
+    float *tap_q, *tap_v, *tap_logp, *tap_qpi, *tap_loss, *tap_g;
+    float* scratch;
+    long long scratch_stride;
+};
+
+size_t rlc_sac_scratch_floats(const RlcSacDims& d);
+// eps_dev: [n_agents][n_updates][B][A] injected N(0,1) draws, or null -> device Philox
+int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st);
+// one state per agent; sample = 0 mean action, 1 reparameterised sample (eps_dev [n][A] or null -> Philox)
+int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
+                       int sample, float* out_dev, hipStream_t st);

@@ -1,0 +1,370 @@
+// sac_generic.hip -- fused SoftActorCritic (SAC-v1) update + acting kernels (any-shape fp32 VALU path).
+//
+// One workgroup per agent, n_updates sequential updates per launch; each update = sample_batch
+// (utils/replaybuffer.py:32-37) + SoftActorCritic_Network_Manager.update_network
+// (agents/SoftActorCritic.py:113-126): ONE Session.run(train_ops) of agents/network/sac_network.py:107-136
+// + update_target_network.  Everything the reference evaluates in that run is computed from the
+// PRE-update weights (pi, Q(s,a), Q(s,pi), V(s), V'(s')), then pi-Adam, then value-Adam, then Polyak.
+// Reference quirks kept (see oracle/sac_oracle.c for the derivation):
+//   Q9   logp_pi is [B] while q_pi, v are [B,1]: v regresses onto q_pi[i] - alpha*mean_j(logp[j]);
+//   the state clip of pi and V uses the SCALARS state_min[0]/state_max[0]; Q sees the raw state;
+//   actions are scaled by action_max[0]; gaussian_likelihood divides by std + 1e-6; the tanh-squash
+//   correction is log(clip(1 - pi^2, 0, 1) + 1e-6) with the clip passing gradients.
+// r and gamma enter fp32 placeholders in this agent (sac_network.py:51-52), so the replay's float64
+// values are cast to fp32 at gather time.
+#include "generic_blocks.h"
+#include "sac_common.h"
+
+namespace {
+
+using namespace gen;
+
+struct SLds {
+    float *x, *xc, *x2c, *a, *api, *eps, *mu, *lsp, *t, *sd, *pit, *dmu, *dls, *r, *g;
+    float *q, *qpi, *v, *vt, *logp, *dout, *red;
+    long long* idx;
+    int* pool;
+    int* dups;
+};
+
+__host__ __device__ inline size_t slds_carve(const RlcSacDims& d, unsigned char* base, SLds* out) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = base ? base + off : nullptr;
+        off += (bytes + 15) & ~(size_t)15;
+        return p;
+    };
+    const int B = d.B, S = d.S, A = d.A;
+    SLds L;
+    L.idx = (long long*)take(sizeof(long long) * RLC_MAX_BATCH);
+    L.x = (float*)take(sizeof(float) * B * S);
+    L.xc = (float*)take(sizeof(float) * B * S);
+    L.x2c = (float*)take(sizeof(float) * B * S);
+    float** pa[] = {&L.a, &L.api, &L.eps, &L.mu, &L.lsp, &L.t, &L.sd, &L.pit, &L.dmu, &L.dls};
+    for (auto p : pa) *p = (float*)take(sizeof(float) * B * A);
+    float** pb[] = {&L.r, &L.g, &L.q, &L.qpi, &L.v, &L.vt, &L.logp, &L.dout};
+    for (auto p : pb) *p = (float*)take(sizeof(float) * B);
+    L.red = (float*)take(sizeof(float) * 16);
+    L.pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
+    L.dups = (int*)take(sizeof(int) * 4);
+    if (out) *out = L;
+    return off;
+}
+
+__device__ __forceinline__ float clip_scalar(float v, int on, float lo, float hi) {
+    return on ? fminf(fmaxf(v, lo), hi) : v;
+}
+
+// block-wide sum of v over threads (fixed order: deterministic); result broadcast to all threads
+__device__ inline float blk_sum(float v, float* red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < kThreads / 64; w++) s += red[w];
+    __syncthreads();
+    return s;
+}
+
+__global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, int first_agent, int n_updates,
+                                                                  int source, const long long* host_idx,
+                                                                  const float* eps_in, int grad_taps) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const RlcSacDims d = dv.d;
+    const int S = d.S, A = d.A, L1A = d.L1A, L2A = d.L2A, L1C = d.L1C, L2C = d.L2C, B = d.B;
+    const int agent = first_agent + blockIdx.x;
+    const int tid = threadIdx.x;
+    SLds L;
+    slds_carve(d, smem, &L);
+    float* th = dv.theta + (size_t)agent * d.Ppad;
+    float* tt = dv.theta_t + (size_t)agent * d.Ppad;
+    float* mm = dv.m + (size_t)agent * d.Ppad;
+    float* vv = dv.v + (size_t)agent * d.Ppad;
+    float* pw = dv.pw + agent * 4;
+    float* tapg = grad_taps ? dv.tap_g + (size_t)agent * d.Ppad : nullptr;
+    const float alpha_ent = dv.alpha[agent], amax0 = dv.amax0;
+    // scratch carve
+    float* sc = dv.scratch + (size_t)agent * dv.scratch_stride;
+    float* ph1 = sc;                sc += (size_t)B * L1A;
+    float* ph2 = sc;                sc += (size_t)B * L2A;
+    float* qh1 = sc;                sc += (size_t)B * L1C;
+    float* qh2 = sc;                sc += (size_t)B * L2C;
+    float* qh2p = sc;               sc += (size_t)B * L2C;
+    float* vh1 = sc;                sc += (size_t)B * L1C;
+    float* vh2 = sc;                sc += (size_t)B * L2C;
+    float* th1 = sc;                sc += (size_t)B * L1C;
+    float* th2 = sc;                sc += (size_t)B * L2C;
+    float* dp2 = sc;                sc += (size_t)B * L2A;
+    float* dp1 = sc;                sc += (size_t)B * L1A;
+    float* dq2 = sc;                sc += (size_t)B * L2C;
+    float* dq1 = sc;                sc += (size_t)B * L1C;
+    float* dv2 = sc;                sc += (size_t)B * L2C;
+    float* dv1 = sc;                sc += (size_t)B * L1C;
+    const float EPS = 1e-6f, LOG2PI = 1.8378770664093453f, HALF_RANGE = 0.5f * (2.0f - (-20.0f));
+
+    for (int u = 0; u < n_updates; u++) {
+        // ---- sample + gather ----
+        const RlcRingMeta ring = dv.rep.ring[agent];
+        if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
+            const unsigned long long call = dv.rep.sample_ctr[agent];
+            __syncthreads();
+            rlc_sample_distinct(ring.size, B, dv.rep.seed[agent], call, L.pool, L.idx, L.dups);
+            if (tid == 0) dv.rep.sample_ctr[agent] = call + 1;
+        } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
+            for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + u) * B + b];
+        }
+        __syncthreads();
+        const unsigned long long nctr = dv.noise_ctr[agent];
+        for (int b = tid; b < B; b += kThreads) {
+            const float *ps, *pa, *ps2;
+            if (source == RLC_SRC_STAGING) {
+                const size_t slot = (size_t)agent * RLC_MAX_BATCH + b;
+                ps = dv.rep.gs + slot * S; pa = dv.rep.ga + slot * A; ps2 = dv.rep.gs2 + slot * S;
+                L.r[b] = (float)dv.rep.gr[slot]; L.g[b] = (float)dv.rep.gg[slot];
+            } else {
+                const size_t slot = (size_t)agent * dv.rep.cap + ring_slot(ring, dv.rep.cap, L.idx[b]);
+                ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot * A; ps2 = dv.rep.rs2 + slot * S;
+                L.r[b] = (float)dv.rep.rr[slot]; L.g[b] = (float)dv.rep.rg[slot];
+            }
+            for (int i = 0; i < S; i++) {
+                L.x[b * S + i] = ps[i];
+                L.xc[b * S + i] = clip_scalar(ps[i], dv.clip_state, dv.smin0, dv.smax0);
+                L.x2c[b * S + i] = clip_scalar(ps2[i], dv.clip_state, dv.smin0, dv.smax0);
+            }
+            for (int j = 0; j < A; j++) {
+                L.a[b * A + j] = pa[j];
+                float e;
+                if (eps_in) {
+                    e = eps_in[(((size_t)blockIdx.x * n_updates + u) * B + b) * A + j];
+                } else {
+                    const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ 0x9E3779B97F4A7C15ull, nctr,
+                                                    (unsigned long long)(b * A + j) >> 1);
+                    float n0, n1;
+                    philox_normal2(p, n0, n1);
+                    e = ((b * A + j) & 1) ? n1 : n0;
+                }
+                L.eps[b * A + j] = e;
+            }
+        }
+        __syncthreads();
+        if (tid == 0 && !eps_in) dv.noise_ctr[agent] = nctr + 1;
+
+        // ---- forward: pi ----
+        blk_dense(L.xc, S, S, nullptr, 0, th + d.pW1, th + d.pb1, L1A, ph1, L1A, B, 1);
+        __syncthreads();
+        blk_dense(ph1, L1A, L1A, nullptr, 0, th + d.pW2, th + d.pb2, L2A, ph2, L2A, B, 1);
+        __syncthreads();
+        blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWm, th + d.pbm, A, L.mu, A, B, 0);
+        blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWs, th + d.pbs, A, L.lsp, A, B, 0);
+        __syncthreads();
+        for (int b = tid; b < B; b += kThreads) {
+            float lp = 0.0f;
+            for (int j = 0; j < A; j++) {
+                const int k = b * A + j;
+                const float t = tanhf(L.lsp[k]);
+                const float log_std = -20.0f + HALF_RANGE * (t + 1.0f);
+                const float sd = expf(log_std);
+                const float uu = L.mu[k] + L.eps[k] * sd;
+                const float z = (uu - L.mu[k]) / (sd + EPS);
+                lp += -0.5f * (z * z + 2.0f * log_std + LOG2PI);
+                const float pt = tanhf(uu);
+                L.t[k] = t; L.sd[k] = sd; L.pit[k] = pt; L.api[k] = pt * amax0;
+            }
+            for (int j = 0; j < A; j++) {
+                const float pt = L.pit[b * A + j];
+                lp -= logf(fminf(fmaxf(1.0f - pt * pt, 0.0f), 1.0f) + 1e-6f);
+            }
+            L.logp[b] = lp;
+            dv.tap_logp[(size_t)agent * RLC_MAX_BATCH + b] = lp;
+        }
+        // ---- forward: Q(s,a), Q(s,pi) (raw state), V(s), V'(s') ----
+        blk_dense(L.x, S, S, nullptr, 0, th + d.qW1, th + d.qb1, L1C, qh1, L1C, B, 1);
+        blk_dense(L.xc, S, S, nullptr, 0, th + d.vW1, th + d.vb1, L1C, vh1, L1C, B, 1);
+        blk_dense(L.x2c, S, S, nullptr, 0, tt + d.vW1, tt + d.vb1, L1C, th1, L1C, B, 1);
+        __syncthreads();
+        blk_dense(qh1, L1C, L1C, L.a, A, th + d.qW2, th + d.qb2, L2C, qh2, L2C, B, 1);
+        blk_dense(qh1, L1C, L1C, L.api, A, th + d.qW2, th + d.qb2, L2C, qh2p, L2C, B, 1);
+        blk_dense(vh1, L1C, L1C, nullptr, 0, th + d.vW2, th + d.vb2, L2C, vh2, L2C, B, 1);
+        blk_dense(th1, L1C, L1C, nullptr, 0, tt + d.vW2, tt + d.vb2, L2C, th2, L2C, B, 1);
+        __syncthreads();
+        blk_dense(qh2, L2C, L2C, nullptr, 0, th + d.qW3, th + d.qb3, 1, L.q, 1, B, 0);
+        blk_dense(qh2p, L2C, L2C, nullptr, 0, th + d.qW3, th + d.qb3, 1, L.qpi, 1, B, 0);
+        blk_dense(vh2, L2C, L2C, nullptr, 0, th + d.vW3, th + d.vb3, 1, L.v, 1, B, 0);
+        blk_dense(th2, L2C, L2C, nullptr, 0, tt + d.vW3, tt + d.vb3, 1, L.vt, 1, B, 0);
+        __syncthreads();
+        float part_lp = 0.0f, part_qp = 0.0f;
+        for (int b = tid; b < B; b += kThreads) { part_lp += L.logp[b]; part_qp += L.qpi[b]; }
+        const float mean_logp = blk_sum(part_lp, L.red) / (float)B;
+        const float mean_qpi = blk_sum(part_qp, L.red) / (float)B;
+        {   // taps + losses (the reference fetches pi_loss, q_loss, v_loss, q, v, logp_pi: sac_network.py:135-136)
+            float ql = 0.0f, vl = 0.0f;
+            for (int b = tid; b < B; b += kThreads) {
+                dv.tap_q[(size_t)agent * RLC_MAX_BATCH + b] = L.q[b];
+                dv.tap_v[(size_t)agent * RLC_MAX_BATCH + b] = L.v[b];
+                dv.tap_qpi[(size_t)agent * RLC_MAX_BATCH + b] = L.qpi[b];
+                const float e = (L.r[b] + L.g[b] * L.vt[b]) - L.q[b];
+                ql += e * e;
+                for (int j = 0; j < B; j++) {
+                    const float f = L.qpi[b] - alpha_ent * L.logp[j] - L.v[b];
+                    vl += f * f;
+                }
+            }
+            ql = blk_sum(ql, L.red);
+            vl = blk_sum(vl, L.red);
+            if (tid == 0) {
+                dv.tap_loss[agent * 4 + 0] = alpha_ent * mean_logp - mean_qpi;
+                dv.tap_loss[agent * 4 + 1] = 0.5f * ql / (float)B;
+                dv.tap_loss[agent * 4 + 2] = 0.5f * vl / ((float)B * (float)B);
+            }
+        }
+
+        // ---- pi backward seeds: d(alpha*mean(logp) - mean(Q(s,pi))) / d(mu_raw, ls_pre) ----
+        for (int it = tid; it < B * A; it += kThreads) {
+            const int b = it / A, j = it % A;
+            float ga = 0.0f;
+            for (int n = 0; n < L2C; n++)
+                if (qh2p[(size_t)b * L2C + n] > 0.0f) ga += th[d.qW3 + n] * th[d.qW2 + (size_t)(L1C + j) * L2C + n];
+            const float pt = L.pit[it], om = 1.0f - pt * pt;
+            const float dlogp_dpit = 2.0f * pt / (fminf(fmaxf(om, 0.0f), 1.0f) + 1e-6f);
+            const float dL_dpit = (-1.0f / (float)B) * ga * amax0 + (alpha_ent / (float)B) * dlogp_dpit;
+            const float dL_du = dL_dpit * om;
+            const float sd = L.sd[it], e = L.eps[it];
+            const float z = e * sd / (sd + EPS);
+            const float dz_dls = e * sd * EPS / ((sd + EPS) * (sd + EPS));
+            const float dL_dlogstd = dL_du * e * sd + (alpha_ent / (float)B) * (-z * dz_dls - 1.0f);
+            L.dmu[it] = dL_du;
+            L.dls[it] = dL_dlogstd * HALF_RANGE * (1.0f - L.t[it] * L.t[it]);
+        }
+        // ---- value backward seeds ----
+        for (int b = tid; b < B; b += kThreads) {
+            L.dout[b] = -((L.r[b] + L.g[b] * L.vt[b]) - L.q[b]) / (float)B;                  // dq_loss/dq
+            L.vt[b] = -(L.qpi[b] - alpha_ent * mean_logp - L.v[b]) / (float)B;               // dv_loss/dv (Q9); vt reused
+        }
+        __syncthreads();
+        // hidden-layer gradients, all with the pre-update weights
+        blk_dense_bwd_input_ex(L.dmu, A, th + d.pWm, ph2, L2A, dp2, B, false);
+        for (int it = tid; it < B * L2C; it += kThreads) {
+            const int b = it / L2C, n = it % L2C;
+            dq2[it] = qh2[it] > 0.0f ? L.dout[b] * th[d.qW3 + n] : 0.0f;
+            dv2[it] = vh2[it] > 0.0f ? L.vt[b] * th[d.vW3 + n] : 0.0f;
+        }
+        __syncthreads();
+        blk_dense_bwd_input_ex(L.dls, A, th + d.pWs, ph2, L2A, dp2, B, true);
+        blk_dense_bwd_input(dq2, L2C, th + d.qW2, qh1, L1C, dq1, B);
+        blk_dense_bwd_input(dv2, L2C, th + d.vW2, vh1, L1C, dv1, B);
+        __syncthreads();
+        blk_dense_bwd_input(dp2, L2A, th + d.pW2, ph1, L1A, dp1, B);
+        __syncthreads();
+        // ---- gradients + Adam: pi optimizer, then value optimizer (disjoint parameters) ----
+        {
+            const AdamCtx cp = {th, mm, vv, adam_alpha(dv.pi_lr[agent], pw[0], pw[1]), tapg};
+            blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dmu, A, B, cp, d.pWm, d.pbm);
+            blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dls, A, B, cp, d.pWs, d.pbs);
+            blk_dense_grad_adam(ph1, L1A, L1A, nullptr, 0, dp2, L2A, B, cp, d.pW2, d.pb2);
+            blk_dense_grad_adam(L.xc, S, S, nullptr, 0, dp1, L1A, B, cp, d.pW1, d.pb1);
+            const AdamCtx cq = {th, mm, vv, adam_alpha(dv.qv_lr[agent], pw[2], pw[3]), tapg};
+            blk_dense_grad_adam(qh2, L2C, L2C, nullptr, 0, L.dout, 1, B, cq, d.qW3, d.qb3);
+            blk_dense_grad_adam(qh1, L1C, L1C, L.a, A, dq2, L2C, B, cq, d.qW2, d.qb2);
+            blk_dense_grad_adam(L.x, S, S, nullptr, 0, dq1, L1C, B, cq, d.qW1, d.qb1);
+            blk_dense_grad_adam(vh2, L2C, L2C, nullptr, 0, L.vt, 1, B, cq, d.vW3, d.vb3);
+            blk_dense_grad_adam(vh1, L1C, L1C, nullptr, 0, dv2, L2C, B, cq, d.vW2, d.vb2);
+            blk_dense_grad_adam(L.xc, S, S, nullptr, 0, dv1, L1C, B, cq, d.vW1, d.vb1);
+        }
+        __syncthreads();
+        if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; pw[2] *= 0.9f; pw[3] *= 0.999f; }
+        // ---- Polyak over every main/target pair (sac_network.py:72-73): (1-tau)*target + tau*main ----
+        for (int p = tid; p < d.Pdev; p += kThreads) tt[p] = (1.0f - dv.tau) * tt[p] + dv.tau * th[p];
+        __syncthreads();
+    }
+}
+
+// mean / sampled action for one state per agent (sac_network.py:327-343): one workgroup per agent
+__global__ __launch_bounds__(kThreads) void rlc_sac_act_kernel(RlcSacDev dv, int first_agent, const float* states,
+                                                               const float* eps_in, int sample, float* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const RlcSacDims d = dv.d;
+    const int S = d.S, A = d.A, L1A = d.L1A, L2A = d.L2A;
+    const int agent = first_agent + blockIdx.x, tid = threadIdx.x;
+    float* x = (float*)smem;
+    float* h1 = x + ((S + 3) & ~3);
+    float* h2 = h1 + ((L1A + 3) & ~3);
+    const float* th = dv.theta + (size_t)agent * d.Ppad;
+    for (int i = tid; i < S; i += kThreads)
+        x[i] = clip_scalar(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin0, dv.smax0);
+    __syncthreads();
+    for (int k = tid; k < L1A; k += kThreads) {
+        float acc = 0.0f;
+        for (int i = 0; i < S; i++) acc += x[i] * th[d.pW1 + i * L1A + k];
+        h1[k] = fmaxf(acc + th[d.pb1 + k], 0.0f);
+    }
+    __syncthreads();
+    for (int n = tid; n < L2A; n += kThreads) {
+        float acc = 0.0f;
+        for (int k = 0; k < L1A; k++) acc += h1[k] * th[d.pW2 + (size_t)k * L2A + n];
+        h2[n] = fmaxf(acc + th[d.pb2 + n], 0.0f);
+    }
+    __syncthreads();
+    const int wave = tid / 64, lane = tid % 64;
+    const unsigned long long nctr = dv.noise_ctr[agent];
+    for (int j = wave; j < A; j += kThreads / 64) {
+        float am = 0.0f, as = 0.0f;
+        for (int n = lane; n < L2A; n += 64) {
+            am += h2[n] * th[d.pWm + n * A + j];
+            as += h2[n] * th[d.pWs + n * A + j];
+        }
+        for (int off = 32; off > 0; off >>= 1) { am += __shfl_down(am, off, 64); as += __shfl_down(as, off, 64); }
+        if (lane == 0) {
+            float u = am + th[d.pbm + j];
+            if (sample) {
+                const float log_std = -20.0f + 0.5f * (2.0f - (-20.0f)) * (tanhf(as + th[d.pbs + j]) + 1.0f);
+                float e;
+                if (eps_in) {
+                    e = eps_in[(size_t)blockIdx.x * A + j];
+                } else {
+                    const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ 0x9E3779B97F4A7C15ull, nctr,
+                                                    0x4000000000000000ull + (unsigned long long)(j >> 1));
+                    float n0, n1;
+                    philox_normal2(p, n0, n1);
+                    e = (j & 1) ? n1 : n0;
+                }
+                u += e * expf(log_std);
+            }
+            out[(size_t)blockIdx.x * A + j] = tanhf(u) * dv.amax0;
+        }
+    }
+    __syncthreads();
+    if (sample && !eps_in && tid == 0) dv.noise_ctr[agent] = nctr + 1;
+}
+
+}  // namespace
+
+size_t rlc_sac_scratch_floats(const RlcSacDims& d) {
+    const size_t B = d.B;
+    return B * ((size_t)2 * d.L1A + 2 * d.L2A + 5 * d.L1C + 6 * d.L2C);
+}
+
+int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st) {
+    const size_t lds = slds_carve(dv.d, nullptr, nullptr);
+    RLC_REQUIRE(lds <= 160 * 1024, "SAC kernel needs %zu B of LDS (> 160 KiB)", lds);
+    static bool attr = false;
+    if (!attr) {
+        RLC_HIP(hipFuncSetAttribute((const void*)rlc_sac_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL(rlc_sac_update_kernel, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates,
+                       source, idx_dev, eps_dev, grad_taps);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
+int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
+                       int sample, float* out_dev, hipStream_t st) {
+    const size_t lds = sizeof(float) * (((dv.d.S + 3) & ~3) + ((dv.d.L1A + 3) & ~3) + ((dv.d.L2A + 3) & ~3));
+    hipLaunchKernelGGL(rlc_sac_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, eps_dev,
+                       sample, out_dev);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}

@@ -11,6 +11,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import check, dptr, f64, fptr, iptr
+from .hip_pop import Population
 
 
 def param_layout(S, A, H1, HA, HC):
@@ -42,7 +43,7 @@ def init_params(S, A, H1, HA, HC, seed):
     return theta
 
 
-class DDPGPopulation(object):
+class DDPGPopulation(Population):
     BLOB = {"theta": 0, "theta_target": 1, "actor_m": 2, "actor_v": 3, "critic_m": 4, "critic_v": 5}
     TAP = {"q": 0, "y": 1, "a_out": 2, "dqda": 3, "grads_c": 4, "grads_a": 5}
     KERNEL = {"auto": 0, "generic": 1, "mfma": 2}
@@ -50,12 +51,8 @@ class DDPGPopulation(object):
     def __init__(self, n_agents, state_dim, action_dim, shared_l1_dim, actor_l2_dim, critic_l2_dim, batch_size,
                  buffer_size, tau, state_min, state_max, action_min, action_max, actor_lr, critic_lr, seeds,
                  clip_state=True, ou_theta=0.15, ou_mu=0.0, ou_sigma=0.2, device=0):
-        self._lib = _lib.load()
-        self._h = ctypes.c_void_p()
-        self.n_agents = int(n_agents)
-        self.S, self.A = int(state_dim), int(action_dim)
+        self._init_base(n_agents, state_dim, action_dim, batch_size)
         self.H1, self.HA, self.HC = int(shared_l1_dim), int(actor_l2_dim), int(critic_l2_dim)
-        self.B = int(batch_size)
         self.layout, self.P = param_layout(self.S, self.A, self.H1, self.HA, self.HC)
         bc = lambda v, n: np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32).reshape(-1), (n,)))
         self._keep = dict(
@@ -77,21 +74,6 @@ class DDPGPopulation(object):
         cfg.seed = self._keep["seed"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
         cfg.ou_theta, cfg.ou_mu, cfg.ou_sigma = float(ou_theta), float(ou_mu), float(ou_sigma)
         check(self._lib.rlc_ddpg_create(ctypes.byref(cfg), ctypes.byref(self._h)))
-
-    # ---- lifetime -------------------------------------------------------------------------
-    def close(self):
-        if getattr(self, "_h", None) is not None and self._h:
-            self._lib.rlc_ddpg_destroy(self._h)
-            self._h = ctypes.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def sync(self):
-        check(self._lib.rlc_ddpg_sync(self._h))
 
     # ---- parameters -----------------------------------------------------------------------
     def set_blob(self, agent, which, values):
@@ -119,47 +101,6 @@ class DDPGPopulation(object):
 
     def named(self, blob):
         return OrderedDict((k, blob[o:o + int(np.prod(s))].reshape(s)) for k, (o, s) in self.layout.items())
-
-    # ---- replay ---------------------------------------------------------------------------
-    def replay_add(self, agent, state, action, reward, next_state, transition_gamma):
-        s, a, s2 = f64(state).reshape(-1), f64(action).reshape(-1), f64(next_state).reshape(-1)
-        if s.size != self.S or s2.size != self.S or a.size != self.A:
-            raise ValueError("transition shapes do not match state_dim/action_dim")
-        check(self._lib.rlc_replay_add(self._h, int(agent), dptr(s), dptr(a), ctypes.c_double(float(reward)),
-                                       dptr(s2), ctypes.c_double(float(transition_gamma))))
-
-    def replay_add_batch(self, agent, states, actions, rewards, next_states, gammas):
-        r = f64(rewards).reshape(-1)
-        n = r.size
-        s, s2 = f64(states).reshape(n, self.S), f64(next_states).reshape(n, self.S)
-        a, g = f64(actions).reshape(n, self.A), f64(gammas).reshape(n)
-        check(self._lib.rlc_replay_add_batch(self._h, int(agent), ctypes.c_int64(n), dptr(s), dptr(a), dptr(r),
-                                             dptr(s2), dptr(g)))
-
-    def replay_fill_all_dev(self, n, s_ptr, a_ptr, r_ptr, s2_ptr, g_ptr):
-        """device pointers (ints), e.g. torch tensor .data_ptr(): fp32 s/a/s2, fp64 r/gamma"""
-        vp = ctypes.c_void_p
-        check(self._lib.rlc_replay_fill_all_dev(self._h, ctypes.c_int64(int(n)), vp(s_ptr), vp(a_ptr), vp(r_ptr),
-                                                vp(s2_ptr), vp(g_ptr)))
-
-    def replay_size(self, agent):
-        out = ctypes.c_int64(0)
-        check(self._lib.rlc_replay_size(self._h, int(agent), ctypes.byref(out)))
-        return int(out.value)
-
-    def replay_gather(self, agent, logical_idx):
-        idx = np.ascontiguousarray(logical_idx, np.int64).reshape(-1)
-        k = idx.size
-        s, s2 = np.empty((k, self.S)), np.empty((k, self.S))
-        a, r, g = np.empty((k, self.A)), np.empty(k), np.empty(k)
-        check(self._lib.rlc_replay_gather(self._h, int(agent), iptr(idx), ctypes.c_int32(k), dptr(s), dptr(a),
-                                          dptr(r), dptr(s2), dptr(g)))
-        return s, a, r, s2, g
-
-    def replay_sample_indices(self, agent, k):
-        out = np.empty(int(k), np.int64)
-        check(self._lib.rlc_replay_sample_indices(self._h, int(agent), ctypes.c_int32(int(k)), iptr(out)))
-        return out
 
     # ---- acting ---------------------------------------------------------------------------
     def act(self, states, first_agent=0, explore=False):
@@ -214,12 +155,3 @@ class DDPGPopulation(object):
         out = np.empty(n, np.float32)
         check(self._lib.rlc_ddpg_last_tap(self._h, int(agent), self.TAP[which], fptr(out), ctypes.c_int64(n)))
         return out
-
-    # ---- timing ---------------------------------------------------------------------------
-    def timer_begin(self):
-        check(self._lib.rlc_timer_begin(self._h))
-
-    def timer_end(self):
-        ms = ctypes.c_float(0.0)
-        check(self._lib.rlc_timer_end(self._h, ctypes.byref(ms)))
-        return float(ms.value)
