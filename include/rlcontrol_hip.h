@@ -37,6 +37,7 @@ extern "C" {
 typedef struct rlc_handle rlc_handle;
 typedef rlc_handle rlc_ddpg;
 typedef rlc_handle rlc_sac;
+typedef rlc_handle rlc_naf;
 
 /* Mirrors what DDPG_Network_Manager.__init__ / BaseNetwork.__init__ read from Config
  * (agents/DDPG.py:17-32, agents/network/base_network.py:14-28, hydra_ddpg_network.py:9-17,
@@ -180,6 +181,44 @@ int rlc_sac_update_batch(rlc_sac* h, int32_t agent, int32_t batch, const double*
  * fetches of train_ops (sac_network.py:135-136); 5 gradient blob (n = P, needs rlc_sac_enable_grad_taps) */
 int rlc_sac_last_tap(rlc_sac* h, int32_t agent, int32_t which, float* dst, int64_t n);
 int rlc_sac_enable_grad_taps(rlc_sac* h, int32_t on);
+
+
+/* ===================================== NAF =========================================================
+ * Mirrors what NAF_Network_Manager.__init__ / NAF_Network.__init__ read from Config (agents/NAF.py:11-21,
+ * agents/network/naf_network.py:6-18; jsonfiles/agent/naf.json).  Parameter blob, variable creation order
+ * (naf_network.py:79-107): W1[S][L1] b1 | Wa2[L1][L2] ba2 | Wa3[L2][A] ba3 | Wv2[L1][L2] bv2 | Wv3[L2] bv3 |
+ * for c < A: Wd_c[L1] bd_c | for c < A-1: Wn_c[L1][A-1-c] bn_c.   blob selector: 0 theta, 1 target, 2 Adam m, 3 Adam v. */
+typedef struct rlc_naf_config {
+    int32_t device, n_agents, state_dim, action_dim;   /* action_dim <= 6 */
+    int32_t l1_dim, l2_dim;                             /* jsonfiles/agent/naf.json:9-10 */
+    int32_t batch_size, clip_state;
+    int64_t buffer_size;
+    float tau;
+    float reserved0;
+    const float* state_min;      /* [state_dim] (naf_network.py:73) */
+    const float* state_max;
+    const float* action_max;     /* [action_dim] scale of tanh (naf_network.py:89) */
+    const float* learning_rate;  /* [n_agents] */
+    const uint64_t* seed;        /* [n_agents] Philox keys of the device sampler */
+} rlc_naf_config;
+
+int rlc_naf_create(const rlc_naf_config* cfg, rlc_naf** out);
+int rlc_naf_param_count(const rlc_naf* h, int64_t* out_p);
+int rlc_naf_set_blob(rlc_naf* h, int32_t agent, int32_t which, const float* src, int64_t n);
+int rlc_naf_get_blob(rlc_naf* h, int32_t agent, int32_t which, float* dst, int64_t n);
+int rlc_naf_get_beta_powers(rlc_naf* h, int32_t agent, float* pw2);
+int rlc_naf_init_target(rlc_naf* h, int32_t agent);                       /* naf_network.py:57-58,178-179 */
+/* predict_action (naf_network.py:144-149): out_mu [n][A]; out_lcols (may be NULL) [n][A(A+1)/2] = the Lmat_columns
+ * fetch of sample_action (:157-158), column c = {exp(clip(diag_c)), below-diagonal entries}: the caller forms
+ * noise_scale * pinv(L L^T) and samples on the host exactly as the reference does (:161-174). */
+int rlc_naf_act(rlc_naf* h, int32_t first_agent, int32_t n, const double* states, float* out_mu, float* out_lcols);
+/* BaseAgent.learn for every agent: sample_batch + NAF_Network_Manager.update_network (agents/NAF.py:69-75) */
+int rlc_naf_update(rlc_naf* h, int32_t n_updates, const int64_t* host_indices);
+int rlc_naf_update_batch(rlc_naf* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+                         const double* next_states, const double* rewards, const double* gammas);
+/* taps of the last update: 0 Q(s,a), 1 TD target y, 2 V(s) (n = batch); 3 gradient blob (n = P) */
+int rlc_naf_last_tap(rlc_naf* h, int32_t agent, int32_t which, float* dst, int64_t n);
+int rlc_naf_enable_grad_taps(rlc_naf* h, int32_t on);
 
 /* -- timing on the handle's stream (hipEvents): bench.py's roofline.achieved */
 int rlc_timer_begin(rlc_handle* h);

@@ -28,6 +28,9 @@ EXPORTS = (
     "rlc_sac_create", "rlc_sac_param_count", "rlc_sac_set_blob", "rlc_sac_get_blob", "rlc_sac_set_beta_powers",
     "rlc_sac_get_beta_powers", "rlc_sac_init_target", "rlc_sac_act", "rlc_sac_update", "rlc_sac_update_batch",
     "rlc_sac_last_tap", "rlc_sac_enable_grad_taps",
+    "rlc_naf_create", "rlc_naf_param_count", "rlc_naf_set_blob", "rlc_naf_get_blob", "rlc_naf_get_beta_powers",
+    "rlc_naf_init_target", "rlc_naf_act", "rlc_naf_update", "rlc_naf_update_batch", "rlc_naf_last_tap",
+    "rlc_naf_enable_grad_taps",
 )
 
 
@@ -63,6 +66,18 @@ class rlc_sac_config(ctypes.Structure):
         ("action_max0", ctypes.c_float),
         ("pi_lr", ctypes.POINTER(ctypes.c_float)), ("qf_vf_lr", ctypes.POINTER(ctypes.c_float)),
         ("entropy_scale", ctypes.POINTER(ctypes.c_float)), ("seed", ctypes.POINTER(ctypes.c_uint64)),
+    ]
+
+
+class rlc_naf_config(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("state_dim", ctypes.c_int32),
+        ("action_dim", ctypes.c_int32), ("l1_dim", ctypes.c_int32), ("l2_dim", ctypes.c_int32),
+        ("batch_size", ctypes.c_int32), ("clip_state", ctypes.c_int32), ("buffer_size", ctypes.c_int64),
+        ("tau", ctypes.c_float), ("reserved0", ctypes.c_float),
+        ("state_min", ctypes.POINTER(ctypes.c_float)), ("state_max", ctypes.POINTER(ctypes.c_float)),
+        ("action_max", ctypes.POINTER(ctypes.c_float)), ("learning_rate", ctypes.POINTER(ctypes.c_float)),
+        ("seed", ctypes.POINTER(ctypes.c_uint64)),
     ]
 
 

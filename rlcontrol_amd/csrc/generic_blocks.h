@@ -136,4 +136,49 @@ __device__ inline void blk_dense_bwd_input_ex(const float* dY, int N, const floa
     }
 }
 
+// ---- variants with an explicit leading dimension of dY (heads that write into a strided slot array) ----
+__device__ inline void blk_dense_bwd_input_ld(const float* dY, int lddy, int N, const float* W, const float* Hk, int K,
+                                              float* dX, int B, bool accumulate) {
+    const int rb = (B + kRows - 1) / kRows;
+    for (int it = threadIdx.x; it < rb * K; it += kThreads) {
+        const int k = it % K;
+        const int b0 = (it / K) * kRows;
+        float acc[kRows];
+#pragma unroll
+        for (int i = 0; i < kRows; i++) acc[i] = 0.0f;
+        for (int n = 0; n < N; n++) {
+            const float w = W[(size_t)k * N + n];
+#pragma unroll
+            for (int i = 0; i < kRows; i++) {
+                const int b = min(b0 + i, B - 1);
+                acc[i] += dY[(size_t)b * lddy + n] * w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRows; i++)
+            if (b0 + i < B) {
+                const size_t p = (size_t)(b0 + i) * K + k;
+                const float v = (Hk == nullptr || Hk[p] > 0.0f) ? acc[i] : 0.0f;
+                dX[p] = accumulate ? dX[p] + v : v;
+            }
+    }
+}
+
+__device__ inline void blk_dense_grad_adam_ld(const float* X, int ldx, int K, const float* dY, int lddy, int N, int B,
+                                              const AdamCtx& c, int oW, int ob) {
+    const int rows = K + 1;   // last "row" is the bias
+    for (int it = threadIdx.x; it < rows * N; it += kThreads) {
+        const int n = it % N;
+        const int k = it / N;
+        float g = 0.0f;
+        if (k < K) {
+            for (int b = 0; b < B; b++) g += X[(size_t)b * ldx + k] * dY[(size_t)b * lddy + n];
+            adam_apply(c, oW + k * N + n, g);
+        } else {
+            for (int b = 0; b < B; b++) g += dY[(size_t)b * lddy + n];
+            adam_apply(c, ob + n, g);
+        }
+    }
+}
+
 }  // namespace gen

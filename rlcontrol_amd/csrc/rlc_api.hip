@@ -132,6 +132,7 @@ int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, 
     memset(&h->rep, 0, sizeof(h->rep));
     memset(&h->dv, 0, sizeof(h->dv));
     memset(&h->sac, 0, sizeof(h->sac));
+    memset(&h->naf, 0, sizeof(h->naf));
     RLC_HIP(hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking));
     (void)hipEventCreate(&h->ev0);
     (void)hipEventCreate(&h->ev1);

@@ -4,6 +4,7 @@
 #pragma once
 #include "rlc_common.h"
 #include "sac_common.h"
+#include "naf_common.h"
 
 enum RlcAlgo { RLC_ALGO_DDPG = 1, RLC_ALGO_SAC = 2, RLC_ALGO_NAF = 3 };
 
@@ -25,6 +26,8 @@ struct rlc_handle {
     int grad_taps;
     // ---- SAC
     RlcSacDev sac;
+    // ---- NAF
+    RlcNafDev naf;
 };
 
 // shared helpers (rlc_api.hip)

@@ -11,6 +11,7 @@ from collections import OrderedDict
 _AGENTS = {
     "DDPG": ("rlcontrol_amd.agents.DDPG", "DDPG"),
     "SoftActorCritic": ("rlcontrol_amd.agents.SoftActorCritic", "SoftActorCritic"),
+    "NAF": ("rlcontrol_amd.agents.NAF", "NAF"),
 }
 
 

@@ -80,10 +80,11 @@ def test_sweep_indexing_first_key_fastest(golden_dir):
     assert p8["actor_lr"] == 0.005 and p8["critic_lr"] == 0.5
 
 
-def test_shipped_ddpg_json_equals_reference_sweep(golden_dir):
-    g = _load(golden_dir, "sweep_params.json")["ddpg"]
+@pytest.mark.parametrize("name", ["ddpg", "sac", "naf"])
+def test_shipped_agent_json_equals_reference_sweep(golden_dir, name):
+    g = _load(golden_dir, "sweep_params.json")[name]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "jsonfiles", "agent", "ddpg.json")) as f:
+    with open(os.path.join(root, "jsonfiles", "agent", name + ".json")) as f:
         mine = json.load(f, object_pairs_hook=OrderedDict)
     assert mine["agent"] == g["agent"]
     assert [list(kv) for kv in mine["sweeps"].items()] == g["sweeps"]

@@ -1,0 +1,153 @@
+"""NAF: oracle trustworthiness on CPU + HIP parity on the GPU (1e-5 on Q, y, V and gradients)."""
+import numpy as np
+import pytest
+
+from oracle.naf import NAFOracle, NafDims, init_params
+
+CASES = [((8, 2, 200, 200), 32), ((3, 1, 64, 48), 17), ((5, 3, 32, 40), 9), ((8, 2, 200, 200), 100)]
+
+
+def _rel(x, y):
+    x, y = np.asarray(x, np.float64).ravel(), np.asarray(y, np.float64).ravel()
+    return float(np.max(np.abs(x - y)) / (np.max(np.abs(y)) + 1e-30))
+
+
+def _bounds(S, A):
+    return -np.ones(S) * 2, np.ones(S) * 2, np.linspace(1.0, 2.0, A)
+
+
+def _batch(rng, B, S, A):
+    return (rng.uniform(-3, 3, (B, S)), rng.uniform(-2, 2, (B, A)), rng.uniform(-3, 3, (B, S)),
+            rng.uniform(-16, 0, B), np.where(rng.rand(B) < 0.2, 0.0, 0.99))
+
+
+def test_naf_param_count_matches_survey():
+    assert NafDims(8, 2, 200, 200).P == 83406
+
+
+@pytest.mark.parametrize("dims,B", CASES)
+def test_naf_oracle_agrees_with_float64_autograd(dims, B):
+    from torch_ref_naf import TorchNAF
+    d = NafDims(*dims)
+    th = init_params(d, 2)
+    smin, smax, amax = _bounds(dims[0], dims[1])
+    o = NAFOracle(d, th, 1e-3, 0.01, smin, smax, amax)
+    t = TorchNAF(dims, th, 1e-3, 0.01, smin, smax, amax)
+    rng = np.random.RandomState(1)
+    s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+    to = o.update(s, a, s2, r, g, taps=True)
+    tt = t.update(s, a, s2, r, g)
+    for k in ("q", "y", "V"):
+        assert _rel(to[k], tt[k]) < 1e-5, k
+    lay, _ = d.layout()
+    for n, (off, shp) in lay.items():
+        assert _rel(to["grads"][off:off + int(np.prod(shp))], tt["grads"][n]) < 2e-5, n
+    assert _rel(o.theta_t, t.blob(True)) < 1e-5
+
+
+def test_naf_loss_is_a_sum_not_a_mean():
+    """naf_network.py:53: dQ seed is 2(q - y), independent of the batch size."""
+    d = NafDims(3, 1, 16, 16)
+    th = init_params(d, 0)
+    smin, smax, amax = _bounds(3, 1)
+    rng = np.random.RandomState(0)
+    s, a, s2, r, g = _batch(rng, 8, 3, 1)
+    o = NAFOracle(d, th, 1e-3, 0.01, smin, smax, amax)
+    t = o.update(s, a, s2, r, g, taps=True)
+    lay, _ = d.layout()
+    assert abs(t["grads"][lay["bv3"][0]] - np.sum(2.0 * (t["q"] - t["y"]))) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _pop(dims, B, n_agents=1, cap=2048, lr=1e-3):
+    from rlcontrol_amd.hip_naf import NAFPopulation
+    S, A, L1, L2 = dims
+    smin, smax, amax = _bounds(S, A)
+    return NAFPopulation(n_agents, S, A, L1, L2, B, cap, 0.01, smin, smax, amax, lr, seeds=list(range(3, 3 + n_agents)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,B", CASES)
+def test_naf_hip_update_matches_oracle(hip_lib, dims, B):
+    d = NafDims(*dims)
+    th = init_params(d, 2)
+    smin, smax, amax = _bounds(dims[0], dims[1])
+    pop = _pop(dims, B)
+    pop.enable_grad_taps(True)
+    pop.set_params(0, th)
+    o = NAFOracle(d, th, 1e-3, 0.01, smin, smax, amax)
+    rng = np.random.RandomState(1)
+    for it in range(3):
+        s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+        pop.update_batch(0, s, a, s2, r, g)
+        t = o.update(s, a, s2, r, g, taps=True)
+        tol = 1e-5 if it == 0 else 2e-4
+        for k in ("q", "y", "V"):
+            assert _rel(pop.last_tap(0, k), t[k]) < tol, (it, k)
+        if it == 0:
+            got = pop.last_tap(0, "grads")
+            lay, _ = d.layout()
+            for n, (off, shp) in lay.items():
+                k = int(np.prod(shp))
+                assert _rel(got[off:off + k], t["grads"][off:off + k]) < 2e-5, n
+            assert _rel(pop.get_blob(0, "theta_target"), o.theta_t) < 1e-5
+            assert np.allclose(pop.get_beta_powers(0), o.pw, rtol=1e-6)
+    pop.close()
+
+
+@pytest.mark.gpu
+def test_naf_hip_replay_path_act_and_agent(hip_lib):
+    dims, B, N = (8, 2, 200, 200), 32, 1500
+    d = NafDims(*dims)
+    smin, smax, amax = _bounds(8, 2)
+    pop = _pop(dims, B, n_agents=2, cap=N)
+    rng = np.random.RandomState(5)
+    data = (rng.uniform(-3, 3, (N, 8)), rng.uniform(-2, 2, (N, 2)), rng.uniform(-16, 0, N), rng.uniform(-3, 3, (N, 8)),
+            np.full(N, 0.99))
+    ths = [init_params(d, 20 + i) for i in range(2)]
+    oracles = []
+    for i in range(2):
+        pop.set_params(i, ths[i])
+        pop.replay_add_batch(i, *data)
+        oracles.append(NAFOracle(d, ths[i], 1e-3, 0.01, smin, smax, amax))
+    idx = np.stack([rng.choice(N, B, replace=False) for _ in range(4)]).reshape(2, 2, B).astype(np.int64)
+    pop.update(2, host_indices=idx)
+    for i in range(2):
+        for k in range(2):
+            j = idx[i, k]
+            t = oracles[i].update(data[0][j], data[1][j], data[3][j], data[2][j], data[4][j], taps=True)
+        for name in ("q", "y", "V"):
+            assert _rel(pop.last_tap(i, name), t[name]) < 2e-4, (i, name)
+    st = rng.uniform(-3, 3, (2, 8))
+    mu, lc = pop.act(st, with_lcols=True)
+    for i in range(2):
+        wm, wl = oracles[i].act(st[i:i + 1])
+        assert _rel(mu[i], wm[0]) < 1e-5 and _rel(lc[i], wl[0]) < 1e-5
+    pop.update(3)                                     # device sampler path
+    assert np.all(np.isfinite(pop.get_blob(1, "theta")))
+    pop.close()
+    # drop-in agent (Pendulum: A = 1) with the reference's host-side covariance sampling
+    from rlcontrol_amd.utils.config import Config
+    from rlcontrol_amd.utils.main_utils import create_agent
+    from rlcontrol_amd.environments.environments import create_environment
+    env = create_environment({"environment": "Pendulum-v0", "TotalMilSteps": 0.001, "EpisodeSteps": -1,
+                              "EvalIntervalMilSteps": 0.0005, "EvalEpisodes": 2})
+    cfg = Config()
+    cfg.merge_config({"env_name": env.name, "state_dim": env.state_dim, "state_min": env.state_min,
+                      "state_max": env.state_max, "action_dim": env.action_dim, "action_min": env.action_min,
+                      "action_max": env.action_max, "norm_type": "input_norm", "exploration_policy": "none",
+                      "l1_dim": 200, "l2_dim": 200, "noise_scale": 0.3, "learning_rate": 0.001, "buffer_size": 5000,
+                      "writer": None, "write_log": False, "write_plot": False, "random_seed": 0})
+    agent = create_agent("NAF", cfg)
+    env.set_random_seed(0)
+    obs = env.reset()
+    agent.reset()
+    a = agent.start(obs, True)
+    for t in range(60):
+        obs_n, r, done, _ = env.step(a)
+        agent.update(obs, obs_n, float(r), a, done, False)
+        a = agent.step(obs_n, True)
+        obs = obs_n
+        assert a.shape == (1,) and abs(a[0]) <= 2.0
+    assert agent.replay_buffer.get_size() == 60
+    assert np.array_equal(agent.start(obs, False), agent.start(obs, False))
