@@ -220,6 +220,44 @@ int rlc_naf_update_batch(rlc_naf* h, int32_t agent, int32_t batch, const double*
 int rlc_naf_last_tap(rlc_naf* h, int32_t agent, int32_t which, float* dst, int64_t n);
 int rlc_naf_enable_grad_taps(rlc_naf* h, int32_t on);
 
+/* ---------------------------------------------------------------------------------------------------
+ * On-device experiment loop: Experiment.run of the reference
+ * (experiment.py:52-217) for every agent of a DDPG population, with the environment simulated on the GPU.
+ * Per training step: act (+OU) -> env.step -> BaseAgent.update (store unless truncated; gamma_i = 0 at
+ * terminals; learn when size > max(warmup_steps, batch_size), agents/base_agent.py:54-70) -> one fused update
+ * (device sampler) -> every eval_interval steps eval_episodes greedy test episodes (which reset the OU noise
+ * mid-episode: quirk Q8).  Evaluation 0 runs before the first training step.  Random streams (environment
+ * resets, OU normals, minibatch indices) are Philox streams keyed by the agent's seed.
+ * ------------------------------------------------------------------------------------------------- */
+#define RLC_ENV_PENDULUM_V0 1          /* gym 0.18 Pendulum-v0 (third-party; restated, float64 simulator) */
+typedef struct rlc_rollout_config {
+    int32_t env_id;                    /* RLC_ENV_PENDULUM_V0 */
+    int32_t episode_steps_limit;       /* EPISODE_STEPS_LIMIT (environments/environments.py:40-46) */
+    int64_t total_steps_limit;         /* TOTAL_STEPS_LIMIT */
+    int64_t eval_interval;             /* training steps between evaluations (>= 1) */
+    int32_t eval_episodes;
+    int32_t warmup_steps;              /* utils/config.py:14 */
+    int32_t max_train_episodes;        /* capacity of the per-agent training-episode log */
+    int32_t reserved0;
+    double gamma;                      /* utils/config.py:15 */
+} rlc_rollout_config;
+
+int rlc_ddpg_rollout_create(rlc_ddpg* h, const rlc_rollout_config* cfg);
+/* advance every agent by up to n_steps training steps (stops at total_steps_limit); returns when the GPU is done.
+ * out_total_steps (may be NULL) receives the training steps taken so far. */
+int rlc_ddpg_rollout_run(rlc_ddpg* h, int64_t n_steps, int64_t* out_total_steps);
+/* counts of one agent: finished training episodes, evaluations run, training steps taken */
+int rlc_rollout_counts(rlc_handle* h, int32_t agent, int64_t* n_train_episodes, int64_t* n_evals,
+                       int64_t* total_steps);
+/* first n finished training episodes: returns, lengths, cumulative step count at the end of each
+ * (train_rewards_per_episode, train_steps_per_episode, train_cum_steps of experiment.py:96-98) */
+int rlc_rollout_train_log(rlc_handle* h, int32_t agent, int64_t n, double* returns, int32_t* lengths,
+                          int64_t* cum_steps);
+/* first n evaluations: returns / lengths [n][eval_episodes] (eval_rewards_per_episode, eval_steps_per_episode) */
+int rlc_rollout_eval_log(rlc_handle* h, int32_t agent, int64_t n, double* returns, int32_t* lengths);
+/* current training observation [state_dim] and episode step of one agent (parity tap) */
+int rlc_rollout_observation(rlc_handle* h, int32_t agent, double* obs, int32_t* episode_step);
+
 /* -- timing on the handle's stream (hipEvents): bench.py's roofline.achieved */
 int rlc_timer_begin(rlc_handle* h);
 int rlc_timer_end(rlc_handle* h, float* out_ms);   /* synchronises on the stop event */

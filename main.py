@@ -10,6 +10,10 @@ INDEX // n_settings, utils/main_utils.py:92-99 + main.py:133-141) and the same r
 (main.py:80-95,188-209; the reference's swapped eval_time/train_time keys are reproduced so the
 offline tooling reads identical fields).  Differences: no TensorFlow summary writer (writer=None),
 and ``--gpu`` picks the HIP device.
+
+``--device_rollout`` runs ALL indices of the range concurrently as one population on the GPU with the
+environment simulated on the device (rlcontrol_amd/device_experiment.py; DDPG on Pendulum-v0): same
+schedule, same pickle, Philox random streams instead of numpy's.
 """
 import argparse
 import json
@@ -49,9 +53,14 @@ def run_index(index, agent_json, env_json, train_env, test_env, env_params, arg_
     experiment = Experiment(agent=agent, train_environment=train_env, test_environment=test_env, seed=random_seed,
                             writer=None, write_log=arg_params["write_log"], write_plot=arg_params["write_plot"],
                             verbose=verbose)
-    (episode_rewards, eval_episode_rewards, train_episode_steps, eval_episode_steps, timesteps_at_eval,
-     train_time, eval_time, train_ep, _) = experiment.run()
+    run_data = _run_data(random_seed, env_json, experiment.run())
+    data["experiment_data"][sweep]["runs"].append(run_data)
+    return run_data
 
+
+def _run_data(random_seed, env_json, result):
+    (episode_rewards, eval_episode_rewards, train_episode_steps, eval_episode_steps, timesteps_at_eval,
+     train_time, eval_time, train_ep, _) = result
     run_data = {"random_seed": random_seed}
     run_data["total_timesteps"] = env_json["TotalMilSteps"] * 1000000
     run_data["eval_interval_timesteps"] = env_json["EvalIntervalMilSteps"] * 1000000
@@ -64,8 +73,59 @@ def run_index(index, agent_json, env_json, train_env, test_env, env_params, arg_
     run_data["total_train_episodes"] = train_ep
     run_data["eval_time"] = train_time      # sic: swapped in the reference (main.py:200-201)
     run_data["train_time"] = eval_time
-    data["experiment_data"][sweep]["runs"].append(run_data)
     return run_data
+
+
+# Config attributes that must be equal across the agents of one device population (everything except the
+# per-agent learning rates and the seed)
+_SHARED_KEYS = ("shared_l1_dim", "actor_l2_dim", "critic_l2_dim", "batch_size", "buffer_size", "tau", "gamma",
+                "warmup_steps", "norm_type", "exploration_policy", "ou_theta", "ou_mu", "ou_sigma")
+
+
+def run_indices_on_device(indices, agent_json, env_json, env_params, arg_params, data, verbose=True, progress=None):
+    """All `indices` at once: one DDPG population per group of indices that share the network / replay shape."""
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
+    if agent_json['agent'] != 'DDPG':
+        raise RuntimeError("--device_rollout is built for the DDPG agent (got %r)" % agent_json['agent'])
+    groups = OrderedDict()
+    for index in indices:
+        agent_params, total_num_sweeps = get_sweep_parameters(agent_json['sweeps'], index)
+        config = Config()
+        config.merge_config(env_params)
+        config.merge_config(agent_params)
+        config.merge_config(dict(arg_params, random_seed=int(index / total_num_sweeps)))
+        if config.exploration_policy != 'ou_noise':
+            raise RuntimeError("the device loop implements the 'ou_noise' exploration policy only")
+        key = tuple(str(getattr(config, k)) for k in _SHARED_KEYS)
+        groups.setdefault(key, []).append((index, index % total_num_sweeps, dict(agent_params), config))
+    out = {}
+    for members in groups.values():
+        c0 = members[0][3]
+        pop = DDPGPopulation(
+            n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, shared_l1_dim=c0.shared_l1_dim,
+            actor_l2_dim=c0.actor_l2_dim, critic_l2_dim=c0.critic_l2_dim, batch_size=c0.batch_size,
+            buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min, state_max=c0.state_max,
+            action_min=c0.action_min, action_max=c0.action_max, actor_lr=[m[3].actor_lr for m in members],
+            critic_lr=[m[3].critic_lr for m in members], seeds=[np.uint64(m[3].random_seed) for m in members],
+            clip_state=(c0.norm_type != 'none'), ou_theta=c0.ou_theta, ou_mu=c0.ou_mu, ou_sigma=c0.ou_sigma,
+            device=int(arg_params.get("device", 0)))
+        for i, m in enumerate(members):
+            pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.shared_l1_dim, c0.actor_l2_dim,
+                                          c0.critic_l2_dim, m[3].random_seed), init_target=True)
+        exp = DeviceExperiment(pop, env_json, gamma=c0.gamma, warmup_steps=c0.warmup_steps)
+        if verbose:
+            print("device rollout: %d agents, %d steps each" % (len(members), exp.total_steps_limit))
+        results = exp.run(progress=progress)
+        for m, res in zip(members, results):
+            out[m[0]] = (m[1], m[2], _run_data(m[3].random_seed, env_json, res))
+        pop.close()
+    for index in indices:            # pickle layout: runs appended in index order, as the sequential driver does
+        sweep, agent_params, run_data = out[index]
+        if sweep not in data["experiment_data"]:
+            data["experiment_data"][sweep] = {"agent_params": agent_params, "runs": []}
+        data["experiment_data"][sweep]["runs"].append(run_data)
+    return data
 
 
 def new_data_dict(agent_json, env_json):
@@ -92,6 +152,8 @@ def main(argv=None):
     parser.add_argument('--save_dir', default="./results")
     parser.add_argument('--gpu', type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
     parser.add_argument('--quiet', default=False, action='store_true')
+    parser.add_argument('--device_rollout', default=False, action='store_true',
+                        help="run all indices concurrently on the GPU with the environment on the device")
     args = parser.parse_args(argv)
 
     arg_params = {"write_log": args.write_log, "write_plot": args.write_plot, "device": args.gpu}
@@ -114,6 +176,14 @@ def main(argv=None):
     }
     data = new_data_dict(agent_json, env_json)
     save_dir = args.save_dir + "/" + env_name + "_" + agent_name + 'results/'
+
+    if args.device_rollout:
+        run_indices_on_device(list(range(args.indices[0], args.indices[2], args.indices[1])), agent_json, env_json,
+                              env_params, arg_params, data, verbose=not args.quiet)
+        os.makedirs(save_dir, exist_ok=True)
+        with open(save_dir + "data_%d_%d_%d.pkl" % tuple(args.indices), "wb") as out_file:
+            pickle.dump(data, out_file)
+        return data
 
     for index in range(args.indices[0], args.indices[2], args.indices[1]):
         run_index(index, agent_json, env_json, train_env, test_env, env_params, arg_params, data,

@@ -31,6 +31,8 @@ EXPORTS = (
     "rlc_naf_create", "rlc_naf_param_count", "rlc_naf_set_blob", "rlc_naf_get_blob", "rlc_naf_get_beta_powers",
     "rlc_naf_init_target", "rlc_naf_act", "rlc_naf_update", "rlc_naf_update_batch", "rlc_naf_last_tap",
     "rlc_naf_enable_grad_taps",
+    "rlc_ddpg_rollout_create", "rlc_ddpg_rollout_run", "rlc_rollout_counts", "rlc_rollout_train_log",
+    "rlc_rollout_eval_log", "rlc_rollout_observation",
 )
 
 
@@ -79,6 +81,19 @@ class rlc_naf_config(ctypes.Structure):
         ("action_max", ctypes.POINTER(ctypes.c_float)), ("learning_rate", ctypes.POINTER(ctypes.c_float)),
         ("seed", ctypes.POINTER(ctypes.c_uint64)),
     ]
+
+
+class rlc_rollout_config(ctypes.Structure):
+    _fields_ = [
+        ("env_id", ctypes.c_int32), ("episode_steps_limit", ctypes.c_int32),
+        ("total_steps_limit", ctypes.c_int64), ("eval_interval", ctypes.c_int64),
+        ("eval_episodes", ctypes.c_int32), ("warmup_steps", ctypes.c_int32),
+        ("max_train_episodes", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("gamma", ctypes.c_double),
+    ]
+
+
+ENV_IDS = {"Pendulum-v0": 1}
 
 
 _lib = None

@@ -12,6 +12,7 @@
 // the headline shapes is ddpg_mfma.hip.  Activations [B,H] live in a per-agent global scratch that
 // stays in the XCD's L2; per-sample vectors live in LDS.
 #include "generic_blocks.h"
+#include "ddpg_rollout_device.h"
 
 namespace {
 
@@ -23,6 +24,7 @@ struct Lds {
     long long* idx;
     int* pool;
     int* dups;
+    float* pol;       // scratch of the on-device training step (ddpg_rollout_device.h)
 };
 
 __host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* base, Lds* out) {
@@ -48,10 +50,11 @@ __host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* bas
     float* dq = (float*)take(sizeof(float) * B);
     int* pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     int* dups = (int*)take(sizeof(int) * 4);
+    float* pol = (float*)take(sizeof(float) * (ddpg_policy_lds_floats(d) + 4));
     if (out) {
         out->r = r; out->g = g; out->idx = idx; out->x = x; out->x2 = x2; out->a = a; out->aout = aout;
         out->mu = mu; out->dqda = dqda; out->dz = dz; out->q = q; out->y = y; out->dq = dq;
-        out->pool = pool; out->dups = dups;
+        out->pool = pool; out->dups = dups; out->pol = pol;
     }
     return off;
 }
@@ -59,7 +62,8 @@ __host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* bas
 __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDev dv, int first_agent,
                                                                            int n_updates, int source,
                                                                            const long long* host_idx,
-                                                                           int grad_taps) {
+                                                                           int grad_taps, const RlcRollout* rollout,
+                                                                           int q8_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcDims d = dv.d;
     const int S = d.S, A = d.A, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
@@ -82,6 +86,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
     float* tap_ga = grad_taps ? dv.tap_ga + (size_t)agent * d.Ppad : nullptr;
 
     for (int u = 0; u < n_updates; u++) {
+        if (rollout) {
+            // on-device experiment loop: one environment step first; update when learn() would run
+            if (!rlc_train_step_device(rollout, agent, L.pol, u == 0 ? q8_first : 0)) continue;
+        }
         // ---- sample + gather (utils/replaybuffer.py:32-37) ----
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
@@ -223,50 +231,18 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_act_kernel(RlcDev dv, int f
                                                                 float* out, int explore) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcDims d = dv.d;
-    const int S = d.S, A = d.A, H1 = d.H1, HA = d.HA;
+    const int S = d.S, A = d.A;
     const int agent = first_agent + blockIdx.x;
     const int tid = threadIdx.x;
-    float* x = (float*)smem;
-    float* h1 = x + ((S + 3) & ~3);
-    float* h2 = h1 + ((H1 + 3) & ~3);
+    const DdpgPolicyLds L = ddpg_policy_carve(d, (float*)smem);
     const float* th = dv.theta + (size_t)agent * d.Ppad;
     for (int i = tid; i < S; i += kThreads)
-        x[i] = clip_state_val(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin[i], dv.smax[i]);
-    __syncthreads();
-    for (int k = tid; k < H1; k += kThreads) {
-        float acc = 0.0f;
-        for (int i = 0; i < S; i++) acc += x[i] * th[d.oW1 + i * H1 + k];
-        h1[k] = fmaxf(acc + th[d.ob1 + k], 0.0f);
-    }
-    __syncthreads();
-    for (int n = tid; n < HA; n += kThreads) {
-        float acc = 0.0f;
-        for (int k = 0; k < H1; k++) acc += h1[k] * th[d.oWa2 + (size_t)k * HA + n];
-        h2[n] = fmaxf(acc + th[d.oba2 + n], 0.0f);
-    }
-    __syncthreads();
-    // one wave per output action: 64-lane shuffle reduction over HA
-    const int wave = tid / RLC_WAVE, lane = tid % RLC_WAVE;
-    for (int j = wave; j < A; j += kThreads / RLC_WAVE) {
-        float acc = 0.0f;
-        for (int n = lane; n < HA; n += RLC_WAVE) acc += h2[n] * th[d.oWa3 + n * A + j];
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, RLC_WAVE);
-        if (lane == 0) {
-            float act = tanhf(acc + th[d.oba3 + j]) * dv.amax[j];
-            if (explore) {
-                // OU: n <- n + N(mu, sigma) - theta*n ; clip(a + n)
-                const unsigned long long ctr = dv.noise_ctr[agent];
-                const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ 0x5DEECE66Dull, ctr, (unsigned long long)(j / 2));
-                float n0, n1;
-                philox_normal2(p, n0, n1);
-                const float z = (j & 1) ? n1 : n0;
-                float noise = dv.ou_state[agent * A + j];
-                noise += (dv.ou_mu + dv.ou_sigma * z) - noise * dv.ou_theta;
-                dv.ou_state[agent * A + j] = noise;
-                act = fminf(fmaxf(act + noise, dv.amin[j]), dv.amax[j]);
-            }
-            out[(size_t)blockIdx.x * A + j] = act;
-        }
+        L.x[i] = clip_state_val(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin[i], dv.smax[i]);
+    ddpg_greedy_forward(d, th, L, dv.amax);
+    if (tid < A) {
+        float act = L.act[tid];
+        if (explore) act = ddpg_ou_explore(dv, agent, tid, act, dv.noise_ctr[agent]);
+        out[(size_t)blockIdx.x * A + tid] = act;
     }
     __syncthreads();
     if (explore && tid == 0) dv.noise_ctr[agent] += 1;
@@ -324,18 +300,19 @@ size_t rlc_generic_scratch_floats(const RlcDims& d) {
 }
 
 int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                                   const long long* idx_dev, int grad_taps, hipStream_t st) {
+                                   const long long* idx_dev, int grad_taps, hipStream_t st, const RlcRollout* rollout,
+                                   int q8_first) {
     const size_t lds = lds_carve(dv.d, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "generic DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
     hipLaunchKernelGGL(rlc_ddpg_update_generic_kernel, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent,
-                       n_updates, source, idx_dev, grad_taps);
+                       n_updates, source, idx_dev, grad_taps, rollout, q8_first);
     RLC_HIP(hipGetLastError());
     return 0;
 }
 
 int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states_dev, float* out_dev, int explore,
                    hipStream_t st) {
-    const size_t lds = sizeof(float) * (((dv.d.S + 3) & ~3) + ((dv.d.H1 + 3) & ~3) + ((dv.d.HA + 3) & ~3));
+    const size_t lds = sizeof(float) * ddpg_policy_lds_floats(dv.d);
     hipLaunchKernelGGL(rlc_ddpg_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, out_dev,
                        explore);
     RLC_HIP(hipGetLastError());

@@ -9,7 +9,7 @@
 #endif
 
 #define RLC_DECL2(M, A_) \
-    int rlc_mfma_launch_##M##_##A_(const RlcDev&, int, int, int, int, const long long*, int, hipStream_t);
+    int rlc_mfma_launch_##M##_##A_(const RlcDev&, int, int, int, int, const long long*, int, hipStream_t, const RlcRollout*, int);
 RLC_FOR_V2(RLC_DECL2)
 
 static inline int mt_for(int B) { return B <= 32 ? 2 : (B <= 64 ? 4 : (B <= 112 ? 7 : 8)); }
@@ -24,12 +24,14 @@ bool rlc_mfma_supported(const RlcDims& d) {
 }
 
 int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                                const long long* idx_dev, int grad_taps, hipStream_t st) {
+                                const long long* idx_dev, int grad_taps, hipStream_t st, const RlcRollout* rollout,
+                                int q8_first) {
     RLC_REQUIRE(rlc_mfma_supported(dv.d), "MFMA kernel does not support these dimensions");
     const int mt = mt_for(dv.d.B);
 #define RLC_CASE2(M, A_)          \
     if (mt == M && dv.d.A == A_)  \
-        return rlc_mfma_launch_##M##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st);
+        return rlc_mfma_launch_##M##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, \
+                                          q8_first);
     RLC_FOR_V2(RLC_CASE2)
 #undef RLC_CASE2
     rlc_set_error("no MFMA instantiation for MT=%d A=%d in this build", mt, dv.d.A);

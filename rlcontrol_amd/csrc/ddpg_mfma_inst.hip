@@ -10,6 +10,8 @@
 #define RLC_CAT(a, b) RLC_CAT_(a, b, 0)
 
 int RLC_CAT(RLC_MT, RLC_AD)(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                            const long long* idx_dev, int grad_taps, hipStream_t st) {
-    return launch_t<RLC_MT, RLC_AD>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st);
+                            const long long* idx_dev, int grad_taps, hipStream_t st, const RlcRollout* rollout,
+                            int q8_first) {
+    return launch_t<RLC_MT, RLC_AD>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout,
+                                    q8_first);
 }

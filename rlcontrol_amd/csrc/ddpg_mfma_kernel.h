@@ -24,6 +24,7 @@
 // Supported shapes: S <= 8, A in {1,2}, H1/HA/HC multiples of 4 in [16,256], B <= 128.
 #pragma once
 #include "rlc_common.h"
+#include "ddpg_rollout_device.h"
 
 namespace {
 
@@ -552,7 +553,8 @@ struct Upd {
 template <int MT, int AD>
 __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev dv, int first_agent, int n_updates,
                                                                         int source, const long long* host_idx,
-                                                                        int grad_taps) {
+                                                                        int grad_taps, const RlcRollout* rollout,
+                                                                        int q8_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using U = Upd<MT, AD>;
     constexpr int MB = U::MB;
@@ -618,6 +620,11 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         // Re-materialise lane geometry every update: without this hipcc hoists the address arithmetic of
         // all ~15 phases out of the update loop and then spills it (190 scratch stores in the prologue).
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));
+        if (rollout) {
+            // on-device experiment loop: one environment step first; the update runs when learn() would
+            // (agents/base_agent.py:65-70).  hbuf is free here (the trunk overwrites it below).
+            if (!rlc_train_step_device(rollout, agent, L.hbuf, upd == 0 ? q8_first : 0)) continue;
+        }
         // ================= sample + gather (utils/replaybuffer.py:32-37) =================
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
@@ -929,7 +936,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 
 template <int MT, int AD>
 int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
-             int grad_taps, hipStream_t st) {
+             int grad_taps, hipStream_t st, const RlcRollout* rollout, int q8_first) {
     const size_t lds = smem_carve(dv.d, MT, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "MFMA DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
     auto kern = rlc_ddpg_update_mfma_kernel<MT, AD>;
@@ -939,7 +946,7 @@ int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates, source, idx_dev,
-                       grad_taps);
+                       grad_taps, rollout, q8_first);
     RLC_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,86 @@
+// ddpg_policy.h -- B=1 greedy forward of the hydra actor + the device OU process, shared by the acting
+// kernel (ddpg_generic.hip), the on-device train step and the on-device evaluation (rollout_kernels.hip).
+// Reference: agents/DDPG.py:34-72 (predict_action on one state), utils/exploration_policy.py:18-24.
+#pragma once
+#include "rlc_common.h"
+
+#ifdef __HIPCC__
+
+#define RLC_POLICY_THREADS 256
+
+// LDS floats needed by ddpg_greedy_forward: x | h1 | h2 | act
+__host__ __device__ inline size_t ddpg_policy_lds_floats(const RlcDims& d) {
+    return (size_t)((d.S + 3) & ~3) + ((d.H1 + 3) & ~3) + ((d.HA + 3) & ~3) + ((d.A + 3) & ~3);
+}
+
+struct DdpgPolicyLds {
+    float *x, *h1, *h2, *act;
+};
+
+__device__ inline DdpgPolicyLds ddpg_policy_carve(const RlcDims& d, float* base) {
+    DdpgPolicyLds L;
+    L.x = base;
+    L.h1 = L.x + ((d.S + 3) & ~3);
+    L.h2 = L.h1 + ((d.H1 + 3) & ~3);
+    L.act = L.h2 + ((d.HA + 3) & ~3);
+    return L;
+}
+
+// L.x holds the clipped state; on return (after the trailing barrier) L.act[j] = tanh(.)*a_max[j].
+// Every thread of the workgroup (any size that is a multiple of 64) must call it.  One thread per output
+// unit, k ascending in one accumulator (the summation order every caller shares); the weight column is
+// fetched KC rows at a time so that KC loads are in flight per thread instead of one dependent chain.
+__device__ inline void ddpg_greedy_forward(const RlcDims& d, const float* th, const DdpgPolicyLds& L,
+                                           const float* amax) {
+    const int S = d.S, A = d.A, H1 = d.H1, HA = d.HA;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    constexpr int KC = 16;
+    __syncthreads();
+    for (int k = tid; k < H1; k += nthr) {
+        float acc = 0.0f;
+        for (int i = 0; i < S; i++) acc += L.x[i] * th[d.oW1 + i * H1 + k];
+        L.h1[k] = fmaxf(acc + th[d.ob1 + k], 0.0f);
+    }
+    __syncthreads();
+    for (int n = tid; n < HA; n += nthr) {
+        const float* wcol = th + d.oWa2 + n;
+        float acc = 0.0f;
+        int k0 = 0;
+        for (; k0 + KC <= H1; k0 += KC) {
+            float w[KC];
+#pragma unroll
+            for (int i = 0; i < KC; i++) w[i] = wcol[(size_t)(k0 + i) * HA];
+#pragma unroll
+            for (int i = 0; i < KC; i++) acc += L.h1[k0 + i] * w[i];
+        }
+        for (; k0 < H1; k0++) acc += L.h1[k0] * wcol[(size_t)k0 * HA];
+        L.h2[n] = fmaxf(acc + th[d.oba2 + n], 0.0f);
+    }
+    __syncthreads();
+    // one wave per output action: 64-lane shuffle reduction over HA
+    const int wave = tid / RLC_WAVE, lane = tid % RLC_WAVE;
+    for (int j = wave; j < A; j += nthr / RLC_WAVE) {
+        float acc = 0.0f;
+        for (int n = lane; n < HA; n += RLC_WAVE) acc += L.h2[n] * th[d.oWa3 + n * A + j];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, RLC_WAVE);
+        if (lane == 0) L.act[j] = tanhf(acc + th[d.oba3 + j]) * amax[j];
+    }
+    __syncthreads();
+}
+
+#define RLC_KEY_OU 0x5DEECE66Dull
+
+// OU step for action component j of one agent: n <- n + N(mu, sigma) - theta*n ; returns clip(a + n)
+// (utils/exploration_policy.py:18-21).  `ctr` = OU draws of this agent so far (one per acting call).
+__device__ inline float ddpg_ou_explore(const RlcDev& dv, int agent, int j, float greedy, unsigned long long ctr) {
+    const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ RLC_KEY_OU, ctr, (unsigned long long)(j / 2));
+    float n0, n1;
+    philox_normal2(p, n0, n1);
+    const float z = (j & 1) ? n1 : n0;
+    float noise = dv.ou_state[agent * dv.d.A + j];
+    noise += (dv.ou_mu + dv.ou_sigma * z) - noise * dv.ou_theta;
+    dv.ou_state[agent * dv.d.A + j] = noise;
+    return fminf(fmaxf(greedy + noise, dv.amin[j]), dv.amax[j]);
+}
+
+#endif  // __HIPCC__

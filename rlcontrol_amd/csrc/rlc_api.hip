@@ -128,6 +128,11 @@ int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, 
     h->io_host = nullptr; h->io_host_cap = 0;
     h->variant = 0;
     h->grad_taps = 0;
+    h->has_env = false;
+    memset(&h->env, 0, sizeof(h->env));
+    h->rollout_dev = nullptr;
+    h->ro_total_limit = h->ro_eval_interval = h->ro_steps = h->ro_evals = 0;
+    h->ro_pending_q8 = 0;
     h->st = nullptr;
     memset(&h->rep, 0, sizeof(h->rep));
     memset(&h->dv, 0, sizeof(h->dv));

@@ -86,6 +86,28 @@ struct RlcReplayDev {
     unsigned long long* sample_ctr;      // [n_agents] sampler invocations so far
 };
 
+// On-device experiment loop (rollout_kernels.hip): environment state, episode bookkeeping and the logs
+// Experiment.run() returns (experiment.py:52-98 of the reference), per agent.
+#define RLC_ENV_PENDULUM RLC_ENV_PENDULUM_V0
+#define RLC_ENV_STATE 4                  // doubles of simulator state per environment instance
+struct RlcEnvDev {
+    int env_id;
+    int episode_limit;                   // EPISODE_STEPS_LIMIT
+    int learn_threshold;                 // max(warmup_steps, batch_size): learn when size > threshold
+    int eval_episodes;
+    int max_episodes, max_evals;         // log capacities per agent
+    double gamma;
+    double* sim;                         // [n_agents][RLC_ENV_STATE] training simulator state
+    double* obs;                         // [n_agents][S] current observation of the training episode
+    int* ep_step;                        // [n_agents]
+    double* ep_ret;                      // [n_agents]
+    int* need_reset;                     // [n_agents] 1 = next train step starts a new episode
+    long long* total_steps;              // [n_agents]
+    unsigned long long* reset_ctr;       // [n_agents] training-environment resets so far
+    double* train_ret; int* train_len; long long* train_cum; int* n_train_ep;   // [n_agents][max_episodes], [n_agents]
+    double* eval_ret; int* eval_len;     // [n_agents][max_evals][eval_episodes]
+};
+
 // Everything the DDPG kernels need; passed by value as a kernel argument (all pointers are device memory).
 struct RlcDev {
     RlcDims d;
@@ -108,6 +130,12 @@ struct RlcDev {
     long long scratch_stride;
 };
 
+// device-resident argument block of a launch that runs training steps (ddpg_rollout_device.h)
+struct RlcRollout {
+    RlcDev dv;
+    RlcEnvDev env;
+};
+
 // where a launch takes its minibatch from
 enum RlcBatchSource { RLC_SRC_REPLAY_DEVICE_SAMPLER = 0, RLC_SRC_REPLAY_HOST_INDICES = 1, RLC_SRC_STAGING = 2 };
 
@@ -115,12 +143,17 @@ enum RlcBatchSource { RLC_SRC_REPLAY_DEVICE_SAMPLER = 0, RLC_SRC_REPLAY_HOST_IND
 // host launchers implemented in the kernel translation units
 // ---------------------------------------------------------------------------------------------
 // generic (any dims) fused update: one workgroup per agent, n_updates sequential updates per launch
+// `rollout` (device pointer, may be null): every iteration first takes one environment step of the on-device
+// experiment loop and skips the update while the learn gate is closed; q8_first flags the first iteration
+// as following an evaluation (OU reset after acting).
 int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                                   const long long* idx_dev, int grad_taps, hipStream_t st);
+                                   const long long* idx_dev, int grad_taps, hipStream_t st,
+                                   const RlcRollout* rollout = nullptr, int q8_first = 0);
 // MFMA-tiled fused update (dims must satisfy rlc_mfma_supported)
 bool rlc_mfma_supported(const RlcDims& d);
 int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                                const long long* idx_dev, int grad_taps, hipStream_t st);
+                                const long long* idx_dev, int grad_taps, hipStream_t st,
+                                const RlcRollout* rollout = nullptr, int q8_first = 0);
 
 // acting / evaluation
 int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states_dev, float* out_dev, int explore,
@@ -128,6 +161,8 @@ int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states
 int rlc_launch_qval(const RlcDev& dv, int agent, int n, const float* states_dev, const float* actions_dev,
                     float* out_dev, hipStream_t st);
 int rlc_launch_reset_noise(const RlcDev& dv, int first_agent, int n, hipStream_t st);
+// on-device experiment loop (rollout_kernels.hip)
+int rlc_launch_ddpg_eval(const RlcDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);
 size_t rlc_generic_scratch_floats(const RlcDims& d);
 // replay
 int rlc_launch_replay_scatter(const RlcReplayDev& rp, int agent, long long first_slot, long long n, const float* s,

@@ -28,6 +28,12 @@ struct rlc_handle {
     RlcSacDev sac;
     // ---- NAF
     RlcNafDev naf;
+    // ---- on-device experiment loop (rlc_api_rollout.hip)
+    bool has_env;
+    RlcEnvDev env;
+    RlcRollout* rollout_dev;             // device copy of {dv, env}: argument block of the fused step launches
+    long long ro_total_limit, ro_eval_interval, ro_steps, ro_evals;
+    int ro_pending_q8;                   // an evaluation ran after the last update: next step resets OU after acting
 };
 
 // shared helpers (rlc_api.hip)
