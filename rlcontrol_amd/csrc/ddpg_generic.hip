@@ -278,8 +278,8 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_qval_kernel(RlcDev dv, int 
     float part = 0.0f;
     for (int n = tid; n < HC; n += kThreads) {
         float acc = 0.0f;
-        for (int k = 0; k < H1; k++) acc += h1[k] * th[d.oWc2 + (size_t)k * HC + n];
-        for (int j = 0; j < A; j++) acc += x[S + j] * th[d.oWc2 + (size_t)(H1 + j) * HC + n];
+        for (int k = 0; k < H1; k++) acc += h1[k] * th[d.oWc2 + rlc_widx(d.blocked, k, n, HC)];
+        for (int j = 0; j < A; j++) acc += x[S + j] * th[d.oWc2 + rlc_widx(d.blocked, H1 + j, n, HC)];
         part += fmaxf(acc + th[d.obc2 + n], 0.0f) * th[d.oWc3 + n];
     }
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, RLC_WAVE);
@@ -303,6 +303,7 @@ int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agen
                                    const long long* idx_dev, int grad_taps, hipStream_t st, const RlcRollout* rollout,
                                    int q8_first) {
     const size_t lds = lds_carve(dv.d, nullptr, nullptr);
+    RLC_REQUIRE(!dv.d.blocked, "the generic kernel reads row-major weights (rlc_ddpg_set_kernel re-packs them)");
     RLC_REQUIRE(lds <= 160 * 1024, "generic DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
     hipLaunchKernelGGL(rlc_ddpg_update_generic_kernel, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent,
                        n_updates, source, idx_dev, grad_taps, rollout, q8_first);

@@ -27,6 +27,7 @@ int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents,
                                 const long long* idx_dev, int grad_taps, hipStream_t st, const RlcRollout* rollout,
                                 int q8_first) {
     RLC_REQUIRE(rlc_mfma_supported(dv.d), "MFMA kernel does not support these dimensions");
+    RLC_REQUIRE(dv.d.blocked, "the MFMA kernel reads tile-blocked weights (rlc_ddpg_set_kernel re-packs them)");
     const int mt = mt_for(dv.d.B);
 #define RLC_CASE2(M, A_)          \
     if (mt == M && dv.d.A == A_)  \

@@ -184,14 +184,18 @@ struct Upd {
             for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         float bcur[NTW][4], bnxt[NTW][4], bnx2[NTW][4];   // weights in flight: this chunk + two ahead
+        // tile-blocked W (rlc_blk_index): block (kc/16, t) holds rows kc..kc+15 of tile t; this lane needs
+        // rows 4g+s of column c -> four dwords 16 B apart inside the block's 1 KB
+        const int lofs = ((((c >> 2) << 4) + 4 * g) << 2) + (c & 3);
         auto loadB = [&](float (&dst)[NTW][4], int kc) {
             const int k0 = kc + 4 * g;
             const bool kval = k0 < K;
 #pragma unroll
-            for (int i = 0; i < NTW; i++)
+            for (int i = 0; i < NTW; i++) {
+                const float* blk = W + ((((size_t)(kc >> 4) * NT + (NTW * wave + i)) << 8) + lofs);
 #pragma unroll
-                for (int s = 0; s < 4; s++)
-                    dst[i][s] = (kval && cval[i]) ? W[(size_t)(k0 + s) * N + col[i]] : 0.0f;
+                for (int s = 0; s < 4; s++) dst[i][s] = (kval && cval[i]) ? blk[4 * s] : 0.0f;
+            }
         };
         loadB(bcur, 0);
         loadB(bnxt, 16);
@@ -221,7 +225,8 @@ struct Upd {
 
     // acc += bias[n] + sum_j E[b][j] * Wx[j][n] ; relu          (E = action rows of the critic concat)
     __device__ __forceinline__ void bias_relu(f32x4 (&acc)[MT][NTW], const float* bias, int N, const float* E,
-                                              const float* Wx /* [AD][N] or null */) {
+                                              const float* Wx /* tile-blocked matrix whose rows xrow0+j multiply E, or null */,
+                                              int xrow0 = 0) {
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
@@ -231,7 +236,7 @@ struct Upd {
             const float bs = ok ? bias[n] : 0.0f;
             float wx[AD];
 #pragma unroll
-            for (int j = 0; j < AD; j++) wx[j] = (ok && Wx) ? Wx[(size_t)j * N + n] : 0.0f;
+            for (int j = 0; j < AD; j++) wx[j] = (ok && Wx) ? Wx[rlc_blk_index(xrow0 + j, n, N)] : 0.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -250,7 +255,8 @@ struct Upd {
     // out[b][j] partial over this wave's columns: sum_n f(acc[b][n]) * coef_j[n]; f = identity or step
     template <bool STEP>
     __device__ __forceinline__ void row_dot(const f32x4 (&acc)[MT][NTW], int N, const float* coef /* [n*cs + j*js] */,
-                                            int cs, int js, const float* coef2 /* optional multiplier [n] */) {
+                                            int cs, int js, const float* coef2 /* optional multiplier [n] */,
+                                            int blk_row0 = -1 /* >= 0: coef is a tile-blocked matrix, rows blk_row0+j */) {
         const int NT = (N + 15) >> 4;
         float cf[NTW][AD];
 #pragma unroll
@@ -260,7 +266,9 @@ struct Upd {
             const bool ok = t < NT && n < N;
 #pragma unroll
             for (int j = 0; j < AD; j++) {
-                float v = ok ? coef[(size_t)n * cs + (size_t)j * js] : 0.0f;
+                float v = ok ? (blk_row0 >= 0 ? coef[rlc_blk_index(blk_row0 + j, n, N)]
+                                              : coef[(size_t)n * cs + (size_t)j * js])
+                             : 0.0f;
                 if (coef2) v *= ok ? coef2[n] : 0.0f;
                 cf[i][j] = v;
             }
@@ -337,13 +345,18 @@ struct Upd {
             for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
 
         f32x4 bcur[NTW], bnxt[NTW], bnx2[NTW];
+        // tile-blocked W: row 16t+c, columns nc+4g..+3 = the 16 bytes of lane g*16+c in block (t, nc/16):
+        // one fully contiguous 1 KB per instruction
+        const int NTk = (Nk + 15) >> 4;
         auto loadB = [&](f32x4 (&dst)[NTW], int nc) {
             const int n0 = nc + 4 * g;
             const bool nval = n0 < Nk;
 #pragma unroll
             for (int i = 0; i < NTW; i++)
-                dst[i] = (nval && rval[i]) ? *reinterpret_cast<const f32x4*>(&W[(size_t)row[i] * Nk + n0])
-                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+                dst[i] = (nval && rval[i])
+                             ? *reinterpret_cast<const f32x4*>(
+                                   &W[(((size_t)(NTW * wave + i) * NTk + (nc >> 4)) << 8) + ((g * 16 + c) << 2)])
+                             : f32x4{0.f, 0.f, 0.f, 0.f};
         };
         loadB(bcur, 0);
         loadB(bnxt, 16);
@@ -465,7 +478,8 @@ struct Upd {
                 for (int q = 0; q < MC; q++) {
                     acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
                     const int kp = 16 * (m0 + q) + c;
-                    const size_t p = (kp < H1 && n4ok) ? (size_t)kp * N + n4 : 0;
+                    // tile-blocked arrays: block (m0+q, t), this lane's 16 bytes at (g*16+c)*16 -> 1 KB per instruction
+                    const size_t p = (kp < H1 && n4ok) ? ((((size_t)(m0 + q) * NT + t) << 8) + ((g * 16 + c) << 2)) : 0;
                     pw_[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
                     pm_[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
                     pv_[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
@@ -505,7 +519,7 @@ struct Upd {
                         nt[r] = pt_[q][r] + tau * (nw[r] - pt_[q][r]);
                     }
                     if (kp < H1 && n4ok) {
-                        const size_t p = (size_t)kp * N + n4;
+                        const size_t p = (((size_t)(m0 + q) * NT + t) << 8) + ((g * 16 + c) << 2);
                         *reinterpret_cast<f32x4*>(&mp[p]) = nm;
                         *reinterpret_cast<f32x4*>(&vp[p]) = nv;
                         *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
@@ -535,7 +549,7 @@ struct Upd {
                 for (int j = 0; j < AD; j++) {
                     const float gr = col4_sum(ge[j]);
                     if (g == j && nok) {
-                        const size_t p = (size_t)(H1 + j) * N + n;
+                        const size_t p = rlc_blk_index(H1 + j, n, N);
                         float mm = mp[p], vv = vp[p];
                         const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
                         mp[p] = mm; vp[p] = vv; Wp[p] = nv;
@@ -673,7 +687,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         __syncthreads();
         STAMP();
         u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
-        u.bias_relu(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2 + (size_t)H1 * HC);
+        u.bias_relu(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2, H1);
         // q' partials: only column j = 0 of the partial buffer is meaningful here
         {
             // reuse row_dot with coef = Wc3' (stride 1, js 0 -> every j gets the same value)
@@ -696,7 +710,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         __syncthreads();
         STAMP();
         u.fwd_gemm(acc, th + d.oWc2, HC, H1);
-        u.bias_relu(acc, th + d.obc2, HC, L.a, th + d.oWc2 + (size_t)H1 * HC);
+        u.bias_relu(acc, th + d.obc2, HC, L.a, th + d.oWc2, H1);
         u.template row_dot<false>(acc, HC, th + d.oWc3, 1, 0, nullptr);           // q partials
         __syncthreads();
         STAMP();
@@ -823,9 +837,9 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 
         // ================= step 5: dQ/da at the scaled action, updated critic (DDPG.py:91) =================
         u.fwd_gemm(acc, th + d.oWc2, HC, H1);
-        u.bias_relu(acc, th + d.obc2, HC, L.aout, th + d.oWc2 + (size_t)H1 * HC);
+        u.bias_relu(acc, th + d.obc2, HC, L.aout, th + d.oWc2, H1);
         // dqda[b][j] = sum_n step(g2[b][n]) * Wc3[n] * Wc2[H1+j][n]
-        u.template row_dot<true>(acc, HC, th + d.oWc2 + (size_t)H1 * HC, 1, HC, th + d.oWc3);
+        u.template row_dot<true>(acc, HC, th + d.oWc2, 1, HC, th + d.oWc3, H1);
         __syncthreads();
         STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {

@@ -13,6 +13,30 @@ __host__ __device__ inline size_t ddpg_policy_lds_floats(const RlcDims& d) {
     return (size_t)((d.S + 3) & ~3) + ((d.H1 + 3) & ~3) + ((d.HA + 3) & ~3) + ((d.A + 3) & ~3);
 }
 
+// column n of a [rows, ncols] weight matrix in either device layout (row-major or tile-blocked, rlc_common.h):
+// at(k0) points at row k0; rows k0+i of the same 16-row block follow at i*step floats.
+struct RlcWCol {
+    const float* p;
+    int step, rowblk, blocked;
+    __device__ __forceinline__ const float* at(int k0) const {
+        return blocked ? p + (size_t)(k0 >> 4) * rowblk + ((k0 & 15) << 2) : p + (size_t)k0 * step;
+    }
+};
+__device__ __forceinline__ RlcWCol rlc_wcol(const float* W, int blocked, int n, int ncols) {
+    RlcWCol w;
+    w.blocked = blocked;
+    if (blocked) {
+        w.p = W + ((n >> 4) << 8) + (((n & 15) >> 2) << 6) + (n & 3);
+        w.step = 4;
+        w.rowblk = ((ncols + 15) >> 4) << 8;
+    } else {
+        w.p = W + n;
+        w.step = ncols;
+        w.rowblk = 0;
+    }
+    return w;
+}
+
 struct DdpgPolicyLds {
     float *x, *h1, *h2, *act;
 };
@@ -43,17 +67,18 @@ __device__ inline void ddpg_greedy_forward(const RlcDims& d, const float* th, co
     }
     __syncthreads();
     for (int n = tid; n < HA; n += nthr) {
-        const float* wcol = th + d.oWa2 + n;
+        const RlcWCol wcol = rlc_wcol(th + d.oWa2, d.blocked, n, HA);
         float acc = 0.0f;
         int k0 = 0;
-        for (; k0 + KC <= H1; k0 += KC) {
+        for (; k0 + KC <= H1; k0 += KC) {     // KC = 16: a chunk never straddles a 16-row block
+            const float* wp = wcol.at(k0);
             float w[KC];
 #pragma unroll
-            for (int i = 0; i < KC; i++) w[i] = wcol[(size_t)(k0 + i) * HA];
+            for (int i = 0; i < KC; i++) w[i] = wp[(size_t)i * wcol.step];
 #pragma unroll
             for (int i = 0; i < KC; i++) acc += L.h1[k0 + i] * w[i];
         }
-        for (; k0 < H1; k0++) acc += L.h1[k0] * wcol[(size_t)k0 * HA];
+        for (; k0 < H1; k0++) acc += L.h1[k0] * *wcol.at(k0);
         L.h2[n] = fmaxf(acc + th[d.oba2 + n], 0.0f);
     }
     __syncthreads();

@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "rlc_handle.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -190,8 +192,12 @@ int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_handle** out) {
     if (rc) { rlc_h_destroy(h); return rc; }
 
     RlcDev& dv = h->dv;
+    // the tile-blocked weight layout goes with the MFMA kernel (the default whenever it supports the shape)
     dv.d = rlc_make_dims(cfg->state_dim, cfg->action_dim, cfg->shared_l1_dim, cfg->actor_l2_dim,
-                         cfg->critic_l2_dim, cfg->batch_size);
+                         cfg->critic_l2_dim, cfg->batch_size, 0);
+    if (rlc_mfma_supported(dv.d))
+        dv.d = rlc_make_dims(cfg->state_dim, cfg->action_dim, cfg->shared_l1_dim, cfg->actor_l2_dim,
+                             cfg->critic_l2_dim, cfg->batch_size, 1);
     dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
     dv.clip_state = cfg->clip_state;
@@ -277,8 +283,8 @@ int rlc_ddpg_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* 
     RLC_REQUIRE(base && src, "bad blob selector %d or null src", which);
     const RlcDims& d = h->dv.d;
     RLC_REQUIRE(n == d.P, "blob length %lld != parameter count %d", (long long)n, d.P);
-    std::vector<float> padded(d.Ppad, 0.0f);     // compact ABI blob -> padded device layout
-    for (int i = 0; i < 10; i++) memcpy(&padded[d.seg_dev[i]], src + d.seg_compact[i], sizeof(float) * d.seg_len[i]);
+    std::vector<float> padded(d.Ppad, 0.0f);     // compact ABI blob -> device layout
+    rlc_pack_blob(d, src, padded.data());
     RLC_HIP(hipMemcpyAsync(base + (size_t)agent * d.Ppad, padded.data(), sizeof(float) * d.Ppad,
                            hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
@@ -290,7 +296,7 @@ static int fetch_blob(rlc_handle* h, const float* dev_src, float* dst) {
     std::vector<float> padded(d.Ppad);
     RLC_HIP(hipMemcpyAsync(padded.data(), dev_src, sizeof(float) * d.Ppad, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
-    for (int i = 0; i < 10; i++) memcpy(dst + d.seg_compact[i], &padded[d.seg_dev[i]], sizeof(float) * d.seg_len[i]);
+    rlc_unpack_blob(d, padded.data(), dst);
     return 0;
 }
 
@@ -526,6 +532,30 @@ static int pick_variant(const rlc_handle* h) {
     return rlc_mfma_supported(h->dv.d) ? 2 : 1;
 }
 
+// Re-pack the six per-agent blobs when the kernel variant (and with it the weight layout) changes.
+static int relayout(rlc_handle* h, int blocked) {
+    if (h->dv.d.blocked == blocked) return 0;
+    if (use_device(h)) return 1;
+    const RlcDims od = h->dv.d;
+    const RlcDims nd = rlc_make_dims(od.S, od.A, od.H1, od.HA, od.HC, od.B, blocked);
+    const size_t NA = h->dv.n_agents, PP = od.Ppad;
+    std::vector<float> dev(NA * PP), compact(od.P), out(NA * PP);
+    for (int which = 0; which < 6; which++) {
+        float* base = blob_ptr(h, which);
+        RLC_HIP(hipMemcpyAsync(dev.data(), base, sizeof(float) * NA * PP, hipMemcpyDeviceToHost, h->st));
+        RLC_HIP(hipStreamSynchronize(h->st));
+        std::fill(out.begin(), out.end(), 0.0f);
+        for (size_t a = 0; a < NA; a++) {
+            rlc_unpack_blob(od, &dev[a * PP], compact.data());
+            rlc_pack_blob(nd, compact.data(), &out[a * PP]);
+        }
+        RLC_HIP(hipMemcpyAsync(base, out.data(), sizeof(float) * NA * PP, hipMemcpyHostToDevice, h->st));
+        RLC_HIP(hipStreamSynchronize(h->st));
+    }
+    h->dv.d = nd;
+    return 0;
+}
+
 static int launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev) {
     const int v = pick_variant(h);
     if (v == 2) {
@@ -590,8 +620,9 @@ int rlc_ddpg_set_kernel(rlc_handle* h, int32_t variant) {
     RLC_NEED_DDPG(h);
     RLC_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (auto), 1 (generic) or 2 (mfma)");
     RLC_REQUIRE(variant != 2 || rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
+    RLC_REQUIRE(!h->has_env, "the kernel variant cannot change once a rollout is attached to the handle");
     h->variant = variant;
-    return 0;
+    return relayout(h, pick_variant(h) == 2 ? 1 : 0);
 }
 
 int rlc_ddpg_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {

@@ -36,37 +36,87 @@ void rlc_set_error(const char* fmt, ...);
 // ---------------------------------------------------------------------------------------------
 // network geometry.  Blob layout = variable creation order of hydra_ddpg_network.py:100-140.
 // ---------------------------------------------------------------------------------------------
+// The two big matrices (Wa2 [H1,HA], Wc2 [H1+A,HC]) and everything shaped like them (target copy, Adam m/v,
+// gradient taps) can be kept in a TILE-BLOCKED device layout: 16x16 blocks, block (tr, tc) at
+// (tr*ceil(cols/16) + tc)*256 floats, and inside a block element (row c, col 4g+r) at ((g*16 + c)*4 + r) --
+// i.e. lane l = g*16+c of a wavefront owns the 16 bytes at l*16.  The MFMA kernel's weight-gradient epilogue
+// (4 arrays read + written per element) and its backward GEMM then move 1 KB CONTIGUOUS per instruction instead
+// of sixteen 64-byte row fragments 800 B apart: 2.7x the per-CU streaming rate (scripts/micro/stream_pattern.hip).
+// The layout is private to the library: the ABI blob is row-major and (un)packed on the host.
+__host__ __device__ inline int rlc_blk_index(int row, int col, int ncols) {
+    const int ntc = (ncols + 15) >> 4;
+    const int c = row & 15, cc = col & 15;
+    return (((row >> 4) * ntc + (col >> 4)) << 8) + ((((cc >> 2) << 4) + c) << 2) + (cc & 3);
+}
+__host__ __device__ inline int rlc_blk_floats(int rows, int cols) { return (((rows + 15) >> 4) * ((cols + 15) >> 4)) << 8; }
+__host__ __device__ inline size_t rlc_widx(int blocked, int row, int col, int ncols) {
+    return blocked ? (size_t)rlc_blk_index(row, col, ncols) : (size_t)row * ncols + col;
+}
+
 struct RlcDims {
     int S, A, H1, HA, HC, B;
+    int blocked;   // 1: Wa2 / Wc2 segments use the tile-blocked layout (MFMA kernel), 0: row-major (generic kernel)
     // DEVICE offsets of the ten tensors inside one agent's blob: each tensor starts on a 256-byte
     // boundary so that rows can be fetched with 16-byte vector loads.  The ABI's compact blob
-    // (rlc_ddpg_set_blob / get_blob) is packed/unpacked on the host with seg_* below.
+    // (rlc_ddpg_set_blob / get_blob) is packed/unpacked on the host with rlc_pack_blob / rlc_unpack_blob.
     int oW1, ob1, oWa2, oba2, oWa3, oba3, oWc2, obc2, oWc3, obc3;
     int P;      // parameter count of the compact ABI blob
-    int Pdev;   // extent of the padded device layout
-    int Ppad;   // per-agent stride of every device blob (= Pdev, multiple of 64 floats)
-    int seg_len[10], seg_compact[10], seg_dev[10];
+    int Pdev;   // extent of the device layout in use
+    int Ppad;   // per-agent stride of every device blob (fits either layout, multiple of 64 floats)
+    int seg_len[10], seg_compact[10], seg_dev[10], seg_rows[10], seg_cols[10];
 };
 
-inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B) {
+inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B, int blocked) {
     RlcDims d;
     d.S = S; d.A = A; d.H1 = H1; d.HA = HA; d.HC = HC; d.B = B;
-    const int len[10] = {S * H1, H1, H1 * HA, HA, HA * A, A, (H1 + A) * HC, HC, HC, 1};
-    int pc = 0, pd = 0;
+    d.blocked = blocked;
+    const int rows[10] = {S, 1, H1, 1, HA, 1, H1 + A, 1, HC, 1};
+    const int cols[10] = {H1, H1, HA, HA, A, A, HC, HC, 1, 1};
+    int pc = 0, pd = 0, pmax = 0;
     for (int i = 0; i < 10; i++) {
-        d.seg_len[i] = len[i];
+        const int len = rows[i] * cols[i];
+        const bool big = i == 2 || i == 6;
+        const int blk = rlc_blk_floats(rows[i], cols[i]);
+        d.seg_len[i] = len; d.seg_rows[i] = rows[i]; d.seg_cols[i] = cols[i];
         d.seg_compact[i] = pc;
         d.seg_dev[i] = pd;
-        pc += len[i];
-        pd += (len[i] + 63) & ~63;
+        pc += len;
+        pd += (((big && blocked) ? blk : len) + 63) & ~63;
+        pmax += ((big ? (blk > len ? blk : len) : len) + 63) & ~63;
     }
     d.oW1 = d.seg_dev[0]; d.ob1 = d.seg_dev[1]; d.oWa2 = d.seg_dev[2]; d.oba2 = d.seg_dev[3];
     d.oWa3 = d.seg_dev[4]; d.oba3 = d.seg_dev[5]; d.oWc2 = d.seg_dev[6]; d.obc2 = d.seg_dev[7];
     d.oWc3 = d.seg_dev[8]; d.obc3 = d.seg_dev[9];
     d.P = pc;
     d.Pdev = pd;
-    d.Ppad = pd;
+    d.Ppad = pmax;
     return d;
+}
+
+// compact row-major ABI blob <-> one agent's device blob (padded is Ppad floats, zero-filled by the caller)
+inline void rlc_pack_blob(const RlcDims& d, const float* compact, float* padded) {
+    for (int i = 0; i < 10; i++) {
+        const float* src = compact + d.seg_compact[i];
+        float* dst = padded + d.seg_dev[i];
+        if (d.blocked && (i == 2 || i == 6)) {
+            for (int r = 0; r < d.seg_rows[i]; r++)
+                for (int c = 0; c < d.seg_cols[i]; c++) dst[rlc_blk_index(r, c, d.seg_cols[i])] = src[(size_t)r * d.seg_cols[i] + c];
+        } else {
+            for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
+        }
+    }
+}
+inline void rlc_unpack_blob(const RlcDims& d, const float* padded, float* compact) {
+    for (int i = 0; i < 10; i++) {
+        float* dst = compact + d.seg_compact[i];
+        const float* src = padded + d.seg_dev[i];
+        if (d.blocked && (i == 2 || i == 6)) {
+            for (int r = 0; r < d.seg_rows[i]; r++)
+                for (int c = 0; c < d.seg_cols[i]; c++) dst[(size_t)r * d.seg_cols[i] + c] = src[rlc_blk_index(r, c, d.seg_cols[i])];
+        } else {
+            for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
+        }
+    }
 }
 
 // Replay ring of ONE agent lives at agent*cap inside each SoA array.  Logical index 0 = oldest.

@@ -65,13 +65,14 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_eval_kernel(RlcDev dv, RlcE
                 float acc[RLC_EVAL_GROUP];
 #pragma unroll
                 for (int e = 0; e < RLC_EVAL_GROUP; e++) acc[e] = 0.0f;
-                const float* wcol = th + d.oWa2 + n;
-                constexpr int KC = 8;                  // weight rows in flight per thread
+                const RlcWCol wcol = rlc_wcol(th + d.oWa2, d.blocked, n, HA);
+                constexpr int KC = 8;                  // weight rows in flight per thread (divides the 16-row blocks)
                 int k0 = 0;
                 for (; k0 + KC <= H1; k0 += KC) {
+                    const float* wp = wcol.at(k0);
                     float w[KC];
 #pragma unroll
-                    for (int i = 0; i < KC; i++) w[i] = wcol[(size_t)(k0 + i) * HA];
+                    for (int i = 0; i < KC; i++) w[i] = wp[(size_t)i * wcol.step];
 #pragma unroll
                     for (int i = 0; i < KC; i++) {
                         const float4* hk = reinterpret_cast<const float4*>(h1 + (k0 + i) * RLC_EVAL_GROUP);
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_eval_kernel(RlcDev dv, RlcE
                     }
                 }
                 for (; k0 < H1; k0++) {
-                    const float w = wcol[(size_t)k0 * HA];
+                    const float w = *wcol.at(k0);
                     const float4* hk = reinterpret_cast<const float4*>(h1 + k0 * RLC_EVAL_GROUP);
 #pragma unroll
                     for (int q = 0; q < RLC_EVAL_GROUP / 4; q++) {
