@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_qval_kernel(RlcDev dv, int 
     for (int n = tid; n < HC; n += kThreads) {
         float acc = 0.0f;
         for (int k = 0; k < H1; k++) acc += h1[k] * th[d.oWc2 + rlc_widx(d.blocked, k, n, HC)];
-        for (int j = 0; j < A; j++) acc += x[S + j] * th[d.oWc2 + rlc_widx(d.blocked, H1 + j, n, HC)];
+        for (int j = 0; j < A; j++) acc += x[S + j] * th[d.oWc2 + rlc_widx(d.blocked, d.arow0 + j, n, HC)];
         part += fmaxf(acc + th[d.obc2 + n], 0.0f) * th[d.oWc3 + n];
     }
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, RLC_WAVE);

@@ -33,7 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;     // two waves per SIMD: one can issue MFMA while the other does VALU / waits on loads
 constexpr int NTW = 2;        // N tiles per wave  (N <= 256)
-constexpr int NT16 = 16;      // mask words per row
+constexpr int NT16 = 16;      // N tiles per row at most (N <= 256)
+// Row stride of the byte masks: 272 B = 68 dwords, so that the dword a lane reads in the backward GEMM
+// (row 16mt+c, bytes nc+4g..+3) sits in bank (4c + g + const) mod 64: conflict-free for all 64 lanes.
+constexpr int MSTRIDE = 16 * NT16 + 16;
 constexpr int MC = 7;         // M' tiles per chunk in the weight-gradient GEMMs
 constexpr int SMAX = 8;
 
@@ -63,7 +66,7 @@ __device__ __forceinline__ float col4_sum(float x) {
 
 struct Smem {
     float* hbuf;
-    unsigned short* mask;
+    unsigned char* mask;   // relu masks, one BYTE (0/1) per (row, unit): [MB][MSTRIDE]
     float* part;      // [kWaves][MB][AD]
     float* wvec;      // [AD][256] staged Wc3 (row 0) or Wa3 transposed
     float *x, *x2, *a, *aout, *mu, *dz, *q, *y, *dq;
@@ -88,11 +91,13 @@ __host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, unsigned 
         return p;
     };
     const int MB = MT * 16, S = d.S, A = d.A, LDH = ldh_for(d.H1);
-    float* hbuf = (float*)take(sizeof(float) * MB * LDH);
+    // + 16 floats of tail: the unmasked fragment reads of the last k-chunk run up to 15 floats past a row's
+    // end (into the next row, or into this zeroed tail after the last row)
+    float* hbuf = (float*)take(sizeof(float) * (MB * LDH + 16));
     double* r = (double*)take(sizeof(double) * MB);
     double* g = (double*)take(sizeof(double) * MB);
     long long* idx = (long long*)take(sizeof(long long) * RLC_MAX_BATCH);
-    unsigned short* mask = (unsigned short*)take(sizeof(unsigned short) * MB * NT16);
+    unsigned char* mask = (unsigned char*)take((size_t)MB * MSTRIDE);
     float* part = (float*)take(sizeof(float) * kWaves * MB * A);
     float* wvec = (float*)take(sizeof(float) * A * 256);
     float* x = (float*)take(sizeof(float) * MB * SMAX);      // rows padded to 8 floats: two ds_read_b128
@@ -163,64 +168,74 @@ struct Upd {
     }
 
     // ---------------------------------------------------------------------------------------
-    // forward GEMM: acc[mt][i] (tile rows 16mt.., cols 16*(wave+4i)..) = hbuf[:, 0:K] . W[0:K, :]
+    // forward GEMM: acc[mt][i] (tile rows 16mt.., cols 16*(2*wave+i)..) = hbuf[:, 0:K] . W[0:K, :]
     // A: one ds_read_b128 per M tile per 16-deep chunk, lane (c,g) holds k = kc+4g+s for step s;
-    // B: W[(kc+4g+s)*N + col] streamed global -> VGPR, next chunk prefetched under the MFMAs.
+    // B: tile-blocked W (rlc_blk_index): block (kc/16, t) holds rows kc..kc+15 of tile t; this lane needs rows
+    //    4g+s of column c -> four dwords 16 B apart inside the block's 1 KB, streamed global -> VGPR.
+    // No masks anywhere in the loop: blocks are zero-padded to 16x16 in memory (rows K..16*ceil(K/16)-1 are
+    // zeros -- Wc2's action rows live in their own block row, RlcDims::arow0), hbuf columns >= H1 are zeros or
+    // finite neighbours (times a zero weight), and the number of tiles a wave owns (2, 1 or 0) is a template
+    // parameter.  Two register sets (A and B fragments of the chunk in flight / the next chunk) alternate in a
+    // loop unrolled by two, so there are no register-rotation moves either: per chunk a wave issues
+    // 7 ds_read_b128 + 4*NOWN global_load_dword + 28*NOWN MFMAs and little else.
     // ---------------------------------------------------------------------------------------
+    template <int NOWN>
+    __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB) {
+        const float* wp = W + ((size_t)(NTW * wave) << 8) + (((((c >> 2) << 4) + 4 * g) << 2) + (c & 3));
+        const size_t wstep = (size_t)NT << 8;                       // floats between block rows
+        const float* ap = L.hbuf + c * LDH + 4 * g;
+        f32x4 a0[MT], a1[MT];
+        float b0[NOWN][4], b1[NOWN][4];
+        auto loadA = [&](f32x4 (&dst)[MT], int ch) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const f32x4*>(ap + 16 * mt * LDH + 16 * ch);
+        };
+        auto loadB = [&](float (&dst)[NOWN][4], int ch) {
+#pragma unroll
+            for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) dst[i][s] = wp[(size_t)ch * wstep + (i << 8) + 4 * s];
+        };
+        auto mac = [&](const f32x4 (&a)[MT], const float (&b)[NOWN][4]) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(a[mt][s], b[i][s], acc[mt][i]);
+        };
+        loadB(b0, 0);
+        loadA(a0, 0);
+        int ch = 0;
+        for (; ch + 2 <= KB; ch += 2) {
+            loadB(b1, ch + 1);
+            loadA(a1, ch + 1);
+            mac(a0, b0);
+            if (ch + 2 < KB) {          // wave-uniform
+                loadB(b0, ch + 2);
+                loadA(a0, ch + 2);
+            }
+            mac(a1, b1);
+        }
+        if (ch < KB) mac(a0, b0);      // odd chunk count: the last chunk is already loaded
+    }
+
     __device__ __forceinline__ void fwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int N, int K) {
         const int NT = (N + 15) >> 4;
-        int col[NTW];
-        bool own[NTW], cval[NTW];
-#pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
-            own[i] = t < NT;
-            col[i] = 16 * t + c;
-            cval[i] = own[i] && col[i] < N;
-        }
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        float bcur[NTW][4], bnxt[NTW][4], bnx2[NTW][4];   // weights in flight: this chunk + two ahead
-        // tile-blocked W (rlc_blk_index): block (kc/16, t) holds rows kc..kc+15 of tile t; this lane needs
-        // rows 4g+s of column c -> four dwords 16 B apart inside the block's 1 KB
-        const int lofs = ((((c >> 2) << 4) + 4 * g) << 2) + (c & 3);
-        auto loadB = [&](float (&dst)[NTW][4], int kc) {
-            const int k0 = kc + 4 * g;
-            const bool kval = k0 < K;
-#pragma unroll
-            for (int i = 0; i < NTW; i++) {
-                const float* blk = W + ((((size_t)(kc >> 4) * NT + (NTW * wave + i)) << 8) + lofs);
-#pragma unroll
-                for (int s = 0; s < 4; s++) dst[i][s] = (kval && cval[i]) ? blk[4 * s] : 0.0f;
-            }
-        };
-        loadB(bcur, 0);
-        loadB(bnxt, 16);
-        for (int kc = 0; kc < K; kc += 16) {
-            loadB(bnx2, kc + 32);      // past-the-end chunks load zeros (predicated off)
-            const bool kval = kc + 4 * g < K;
-            f32x4 av[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(&L.hbuf[(16 * mt + c) * LDH + kc + 4 * g]);
-                av[mt] = kval ? t : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int i = 0; i < NTW; i++)
-                    if (own[i]) {
-#pragma unroll
-                        for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], bcur[i][s], acc[mt][i]);
-                    }
-#pragma unroll
-            for (int i = 0; i < NTW; i++)
-#pragma unroll
-                for (int s = 0; s < 4; s++) { bcur[i][s] = bnxt[i][s]; bnxt[i][s] = bnx2[i][s]; }
-        }
+#ifdef RLC_STAMPS
+        const long long t_w0 = clock64();
+#endif
+        const int nown = NT - NTW * wave;          // tiles this wave owns: wave-uniform
+        const int KB = (K + 15) >> 4;
+        if (nown >= 2) fwd_loop<2>(acc, W, NT, KB);
+        else if (nown == 1) fwd_loop<1>(acc, W, NT, KB);
+#ifdef RLC_STAMPS
+        if (lane == 0 && stamp_buf) stamp_buf[48 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
+#endif
     }
 
     // acc += bias[n] + sum_j E[b][j] * Wx[j][n] ; relu          (E = action rows of the critic concat)
@@ -298,7 +313,7 @@ struct Upd {
         return s;
     }
 
-    // relu masks of the accumulators -> mask16[b][tile]
+    // relu masks of the accumulators -> one byte per (row, unit)
     __device__ __forceinline__ void store_masks(const f32x4 (&acc)[MT][NTW], int N) {
         const int NT = (N + 15) >> 4;
 #pragma unroll
@@ -308,10 +323,8 @@ struct Upd {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const unsigned long long bal = __ballot(acc[mt][i][r] > 0.0f);
-                        if (c == 0) L.mask[(16 * mt + 4 * g + r) * NT16 + t] = (unsigned short)(bal >> (16 * g));
-                    }
+                    for (int r = 0; r < 4; r++)
+                        L.mask[(16 * mt + 4 * g + r) * MSTRIDE + 16 * t + c] = acc[mt][i][r] > 0.0f ? 1 : 0;
             }
         }
     }
@@ -319,78 +332,92 @@ struct Upd {
     // ---------------------------------------------------------------------------------------
     // backward-to-input GEMM: acc[b][k'] = sum_n D[b][n] * W[k'][n],  D[b][n] = mask(b,n) * sum_j seed[b][j]*wv[j][n]
     // (D is never materialised).  k-dim = n in chunks of 16 with lane (c,g) taking n = nc+4g+s:
-    //   A  from mask16 + seed (registers) + wvec (LDS);  B = one dwordx4 of row k' of W per chunk.
+    //   B = the lane's 16 bytes of block (t, nc/16) of the tile-blocked W: 1 KB contiguous per instruction;
+    //   A = the relu mask bytes of row 16mt+c (one ds_read_b32 -> four v_cvt_f32_ubyte).
+    // NS == 1 (critic always, actor when A == 1): D is rank one, so the seed leaves the loop --
+    //   acc[b][k'] = seed[b] * sum_n maskf(b,n) * (wv[n] W[k'][n]):  A = the 0/1 mask floats as they are, B is
+    //   scaled by wv (4 multiplies per tile per chunk) and the rows are scaled by seed[b] once at the end.
+    // Same structure as fwd_loop: tiles owned is a template parameter, two register sets, no masks.
     // ---------------------------------------------------------------------------------------
-    template <int NS>
-    __device__ __forceinline__ void bwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int Nk /* row length = k-dim */,
-                                             int Kout /* rows of W used = H1 */, const float* seed /* LDS [MB][NS] */) {
-        const int NT = (Kout + 15) >> 4;
-        int row[NTW];
-        bool own[NTW], rval[NTW];
-#pragma unroll
-        for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
-            own[i] = t < NT;
-            row[i] = 16 * t + c;
-            rval[i] = own[i] && row[i] < Kout;
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    template <int NS, int NOWN>
+    __device__ __forceinline__ void bwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NTk, const float* seed) {
+        const float* wp = W + (((size_t)(NTW * wave) * NTk) << 8) + (lane << 2);
+        const unsigned char* mp = L.mask + c * MSTRIDE + 4 * g;
+        const float* wvp = L.wvec + 4 * g;
         float sd[MT][NS];
+        if (NS > 1) {
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-            for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
-
-        f32x4 bcur[NTW], bnxt[NTW], bnx2[NTW];
-        // tile-blocked W: row 16t+c, columns nc+4g..+3 = the 16 bytes of lane g*16+c in block (t, nc/16):
-        // one fully contiguous 1 KB per instruction
-        const int NTk = (Nk + 15) >> 4;
-        auto loadB = [&](f32x4 (&dst)[NTW], int nc) {
-            const int n0 = nc + 4 * g;
-            const bool nval = n0 < Nk;
+                for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
+        }
+        f32x4 b0[NOWN], b1[NOWN];
+        auto loadB = [&](f32x4 (&dst)[NOWN], int ch) {
 #pragma unroll
-            for (int i = 0; i < NTW; i++)
-                dst[i] = (nval && rval[i])
-                             ? *reinterpret_cast<const f32x4*>(
-                                   &W[(((size_t)(NTW * wave + i) * NTk + (nc >> 4)) << 8) + ((g * 16 + c) << 2)])
-                             : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < NOWN; i++)
+                dst[i] = *reinterpret_cast<const f32x4*>(wp + (((size_t)i * NTk + ch) << 8));
         };
-        loadB(bcur, 0);
-        loadB(bnxt, 16);
-        for (int nc = 0; nc < Nk; nc += 16) {
-            loadB(bnx2, nc + 32);      // past-the-end chunks load zeros (predicated off)
-            const int n0 = nc + 4 * g;
-            const bool nval = n0 < Nk;
-            f32x4 wv[NS];
+        auto mac = [&](const f32x4 (&bin)[NOWN], int ch) {
+            f32x4 wv[NS], b[NOWN];
 #pragma unroll
-            for (int j = 0; j < NS; j++)
-                wv[j] = nval ? *reinterpret_cast<const f32x4*>(&L.wvec[j * 256 + n0]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NS; j++) wv[j] = *reinterpret_cast<const f32x4*>(wvp + j * 256 + 16 * ch);
+#pragma unroll
+            for (int i = 0; i < NOWN; i++) b[i] = NS == 1 ? bin[i] * wv[0] : bin[i];
             f32x4 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                const unsigned m = L.mask[(16 * mt + c) * NT16 + (nc >> 4)];
+                const unsigned mw = *reinterpret_cast<const unsigned*>(mp + 16 * mt * MSTRIDE + 16 * ch);
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    float v = 0.0f;
+                    const float f = (float)((mw >> (8 * s)) & 0xffu);        // v_cvt_f32_ubyte<s>: 0.0 or 1.0
+                    if (NS == 1) {
+                        av[mt][s] = f;
+                    } else {
+                        float v = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < NS; j++) v += sd[mt][j] * wv[j][s];
-                    av[mt][s] = ((m >> (4 * g + s)) & 1u) ? v : 0.0f;
+                        for (int j = 0; j < NS; j++) v += sd[mt][j] * wv[j][s];
+                        av[mt][s] = f * v;
+                    }
                 }
             }
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int i = 0; i < NTW; i++)
-                    if (own[i]) {
+                for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                        for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], bcur[i][s], acc[mt][i]);
-                    }
-#pragma unroll
-            for (int i = 0; i < NTW; i++) { bcur[i] = bnxt[i]; bnxt[i] = bnx2[i]; }
+                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], b[i][s], acc[mt][i]);
+        };
+        loadB(b0, 0);
+        int ch = 0;
+        for (; ch + 2 <= NTk; ch += 2) {
+            loadB(b1, ch + 1);
+            mac(b0, ch);
+            if (ch + 2 < NTk) loadB(b0, ch + 2);      // wave-uniform
+            mac(b1, ch + 1);
         }
+        if (ch < NTk) mac(b0, ch);
+        if (NS == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const f32x4 sv = *reinterpret_cast<const f32x4*>(&seed[16 * mt + 4 * g]);
+#pragma unroll
+                for (int i = 0; i < NOWN; i++) acc[mt][i] = acc[mt][i] * sv;
+            }
+        }
+    }
+
+    template <int NS>
+    __device__ __forceinline__ void bwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int Nk /* row length = k-dim */,
+                                             int Kout /* rows of W used = H1 */, const float* seed /* LDS [MB][NS] */) {
+        const int NT = (Kout + 15) >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nown = NT - NTW * wave;
+        const int NTk = (Nk + 15) >> 4;
+        if (nown >= 2) bwd_loop<NS, 2>(acc, W, NTk, seed);
+        else if (nown == 1) bwd_loop<NS, 1>(acc, W, NTk, seed);
     }
 
     // epilogue of bwd_gemm: dh1 = acc * (hbuf > 0); column-reduce into the W1 / b1 gradients of this wave's
@@ -493,15 +520,14 @@ struct Upd {
                     float dv = 0.0f;
 #pragma unroll
                     for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
-                    const unsigned mword = L.mask[b * NT16 + t];
-                    const float df = ((mword >> c) & 1u) ? dv : 0.0f;
-                    // hbuf fragments: branch-free (clamped address + select) so the LDS reads issue together
+                    const float df = L.mask[b * MSTRIDE + 16 * t + c] ? dv : 0.0f;
+                    // hbuf fragments, unmasked: columns kp >= H1 (last tile only; rows past NMT of the chunk clamp
+                    // to tile 0) only feed accumulator rows that are never stored
                     float hf[MC];
 #pragma unroll
                     for (int q = 0; q < MC; q++) {
-                        const int kp = 16 * (m0 + q) + c;
-                        const float hv = L.hbuf[b * LDH + (kp < H1 ? kp : 0)];
-                        hf[q] = kp < H1 ? hv : 0.0f;
+                        const int kq = (m0 + q < NMT) ? 16 * (m0 + q) : 0;          // wave-uniform clamp
+                        hf[q] = L.hbuf[b * LDH + kq + c];
                     }
 #pragma unroll
                     for (int q = 0; q < MC; q++) acc[q] = mfma16(df, hf[q], acc[q]);
@@ -540,8 +566,7 @@ struct Upd {
                     float dv = 0.0f;
 #pragma unroll
                     for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
-                    const unsigned mword = L.mask[b * NT16 + t];
-                    const float dd = ((mword >> c) & 1u) ? dv : 0.0f;
+                    const float dd = L.mask[b * MSTRIDE + 16 * t + c] ? dv : 0.0f;
 #pragma unroll
                     for (int j = 0; j < AD; j++) ge[j] += E[b * AD + j] * dd;
                 }
@@ -549,7 +574,7 @@ struct Upd {
                 for (int j = 0; j < AD; j++) {
                     const float gr = col4_sum(ge[j]);
                     if (g == j && nok) {
-                        const size_t p = rlc_blk_index(H1 + j, n, N);
+                        const size_t p = rlc_blk_index(((H1 + 15) & ~15) + j, n, N);   // RlcDims::arow0 + j
                         float mm = mp[p], vv = vp[p];
                         const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
                         mp[p] = mm; vp[p] = vv; Wp[p] = nv;
@@ -606,7 +631,8 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     for (int i = tid; i < MB * AD; i += kThreads) { L.a[i] = 0.f; L.aout[i] = 0.f; L.mu[i] = 0.f; L.dz[i] = 0.f; }
     for (int i = tid; i < MB * SMAX; i += kThreads) { L.x[i] = 0.f; L.x2[i] = 0.f; }
     for (int i = tid; i < MB; i += kThreads) { L.q[i] = 0.f; L.y[i] = 0.f; L.dq[i] = 0.f; }
-    for (int i = tid; i < MB * NT16; i += kThreads) L.mask[i] = 0;
+    for (int i = tid; i < MB * MSTRIDE / 4; i += kThreads) reinterpret_cast<unsigned int*>(L.mask)[i] = 0u;
+    if (tid < 16) L.hbuf[MB * u.LDH + tid] = 0.0f;
     __syncthreads();
 
     f32x4 acc[MT][NTW];
@@ -687,7 +713,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         __syncthreads();
         STAMP();
         u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
-        u.bias_relu(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2, H1);
+        u.bias_relu(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2, d.arow0);
         // q' partials: only column j = 0 of the partial buffer is meaningful here
         {
             // reuse row_dot with coef = Wc3' (stride 1, js 0 -> every j gets the same value)
@@ -710,7 +736,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         __syncthreads();
         STAMP();
         u.fwd_gemm(acc, th + d.oWc2, HC, H1);
-        u.bias_relu(acc, th + d.obc2, HC, L.a, th + d.oWc2, H1);
+        u.bias_relu(acc, th + d.obc2, HC, L.a, th + d.oWc2, d.arow0);
         u.template row_dot<false>(acc, HC, th + d.oWc3, 1, 0, nullptr);           // q partials
         __syncthreads();
         STAMP();
@@ -837,9 +863,9 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 
         // ================= step 5: dQ/da at the scaled action, updated critic (DDPG.py:91) =================
         u.fwd_gemm(acc, th + d.oWc2, HC, H1);
-        u.bias_relu(acc, th + d.obc2, HC, L.aout, th + d.oWc2, H1);
+        u.bias_relu(acc, th + d.obc2, HC, L.aout, th + d.oWc2, d.arow0);
         // dqda[b][j] = sum_n step(g2[b][n]) * Wc3[n] * Wc2[H1+j][n]
-        u.template row_dot<true>(acc, HC, th + d.oWc2, 1, HC, th + d.oWc3, H1);
+        u.template row_dot<true>(acc, HC, th + d.oWc2, 1, HC, th + d.oWc3, d.arow0);
         __syncthreads();
         STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {

@@ -56,6 +56,9 @@ __host__ __device__ inline size_t rlc_widx(int blocked, int row, int col, int nc
 struct RlcDims {
     int S, A, H1, HA, HC, B;
     int blocked;   // 1: Wa2 / Wc2 segments use the tile-blocked layout (MFMA kernel), 0: row-major (generic kernel)
+    int arow0;     // device row of Wc2's first action row: H1 (row-major) or the next multiple of 16 (blocked), so
+                   // that in the blocked layout the trunk rows H1..arow0-1 are zero padding and the k-loops of the
+                   // forward GEMMs need no row mask
     // DEVICE offsets of the ten tensors inside one agent's blob: each tensor starts on a 256-byte
     // boundary so that rows can be fetched with 16-byte vector loads.  The ABI's compact blob
     // (rlc_ddpg_set_blob / get_blob) is packed/unpacked on the host with rlc_pack_blob / rlc_unpack_blob.
@@ -70,13 +73,14 @@ inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B, int bl
     RlcDims d;
     d.S = S; d.A = A; d.H1 = H1; d.HA = HA; d.HC = HC; d.B = B;
     d.blocked = blocked;
+    d.arow0 = blocked ? ((H1 + 15) & ~15) : H1;
     const int rows[10] = {S, 1, H1, 1, HA, 1, H1 + A, 1, HC, 1};
     const int cols[10] = {H1, H1, HA, HA, A, A, HC, HC, 1, 1};
     int pc = 0, pd = 0, pmax = 0;
     for (int i = 0; i < 10; i++) {
         const int len = rows[i] * cols[i];
         const bool big = i == 2 || i == 6;
-        const int blk = rlc_blk_floats(rows[i], cols[i]);
+        const int blk = rlc_blk_floats(i == 6 ? ((H1 + 15) & ~15) + A : rows[i], cols[i]);
         d.seg_len[i] = len; d.seg_rows[i] = rows[i]; d.seg_cols[i] = cols[i];
         d.seg_compact[i] = pc;
         d.seg_dev[i] = pd;
@@ -93,6 +97,11 @@ inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B, int bl
     return d;
 }
 
+// logical row -> device row of segment i (only Wc2's action rows move, see RlcDims::arow0)
+__host__ __device__ inline int rlc_dev_row(const RlcDims& d, int seg, int r) {
+    return (seg == 6 && r >= d.H1) ? d.arow0 + (r - d.H1) : r;
+}
+
 // compact row-major ABI blob <-> one agent's device blob (padded is Ppad floats, zero-filled by the caller)
 inline void rlc_pack_blob(const RlcDims& d, const float* compact, float* padded) {
     for (int i = 0; i < 10; i++) {
@@ -100,7 +109,8 @@ inline void rlc_pack_blob(const RlcDims& d, const float* compact, float* padded)
         float* dst = padded + d.seg_dev[i];
         if (d.blocked && (i == 2 || i == 6)) {
             for (int r = 0; r < d.seg_rows[i]; r++)
-                for (int c = 0; c < d.seg_cols[i]; c++) dst[rlc_blk_index(r, c, d.seg_cols[i])] = src[(size_t)r * d.seg_cols[i] + c];
+                for (int c = 0; c < d.seg_cols[i]; c++)
+                    dst[rlc_blk_index(rlc_dev_row(d, i, r), c, d.seg_cols[i])] = src[(size_t)r * d.seg_cols[i] + c];
         } else {
             for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
         }
@@ -112,7 +122,8 @@ inline void rlc_unpack_blob(const RlcDims& d, const float* padded, float* compac
         const float* src = padded + d.seg_dev[i];
         if (d.blocked && (i == 2 || i == 6)) {
             for (int r = 0; r < d.seg_rows[i]; r++)
-                for (int c = 0; c < d.seg_cols[i]; c++) dst[(size_t)r * d.seg_cols[i] + c] = src[rlc_blk_index(r, c, d.seg_cols[i])];
+                for (int c = 0; c < d.seg_cols[i]; c++)
+                    dst[(size_t)r * d.seg_cols[i] + c] = src[rlc_blk_index(rlc_dev_row(d, i, r), c, d.seg_cols[i])];
         } else {
             for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
         }

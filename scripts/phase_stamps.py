@@ -47,6 +47,8 @@ def main():
     print("stamped cycles/update %.0f (%.1f us at 2.4 GHz)" % (tot.sum(), tot.sum() / 2400))
     for n, c in zip(NAMES, tot):
         print("  %-24s %9.0f cyc  %5.1f %%" % (n, c, 100 * c / tot.sum()))
+    pw = pop.last_tap(0, "grads_c")[48:56] / U / 5
+    print("  forward-GEMM k-loop cycles per wave (mean of the 5 GEMMs): " + " ".join("%.0f" % v for v in pw))
     sub = pop.last_tap(0, "grads_c")[21:25] / U
     print("  wave-0 inside both wgrad GEMMs: prefetch-issue %.0f, k-loop %.0f, epilogue(+next prefetch wait) %.0f, action rows %.0f" % tuple(sub))
 
