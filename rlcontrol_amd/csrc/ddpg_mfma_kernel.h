@@ -666,12 +666,15 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             if (!rlc_train_step_device(rollout, agent, L.hbuf, upd == 0 ? q8_first : 0)) continue;
         }
         // ================= sample + gather (utils/replaybuffer.py:32-37) =================
+        u.sub_begin();
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
             const unsigned long long call = dv.rep.sample_ctr[agent];
             __syncthreads();
+            u.sub_stamp(25);
             rlc_sample_distinct(ring.size, B, dv.rep.seed[agent], call, L.pool, L.idx, L.dups);
             if (tid == 0) dv.rep.sample_ctr[agent] = call + 1;
+            u.sub_stamp(26);
         } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
             for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + upd) * B + b];
         }
@@ -694,6 +697,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #pragma unroll
             for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
         }
+        u.sub_stamp(27);
         __syncthreads();
         STAMP();
 

@@ -320,6 +320,7 @@ __device__ __forceinline__ float adam_alpha(float lr, float b1p, float b2p) {
 // dense regime (3k >= n, as in sample_n_k): partial Fisher-Yates over an LDS copy of range(n);
 // sparse regime: one candidate per thread, duplicates (against lower-numbered threads) redrawn
 // until none remain -- equivalent in distribution to sequential sampling without replacement.
+// Every thread of the workgroup must call it; blockDim.x must be a multiple of RLC_MAX_BATCH (128).
 __device__ inline void rlc_sample_distinct(long long n, int k, unsigned long long key, unsigned long long call,
                                            int* lds_pool /* >= 3*RLC_MAX_BATCH ints */, long long* out /* LDS, k */,
                                            int* lds_dups /* 1 int */) {
@@ -339,24 +340,34 @@ __device__ inline void rlc_sample_distinct(long long n, int k, unsigned long lon
         __syncthreads();
         return;
     }
+    // sparse regime.  Candidate t (t < k) is thread t's; the duplicate test "some j < t holds the same value"
+    // is spread over the whole workgroup: thread (t + 128*p) scans j in [32p', ...) -- no data-dependent
+    // exits, broadcast LDS reads -- and the verdicts are combined through one LDS word.
     long long mine = -1;
     unsigned int round = 0;
     bool need = tid < k;
+    int* flag = lds_pool;                     // k ints (the dense regime's pool is free here)
+    const int t = tid & (RLC_MAX_BATCH - 1);
+    const int part = tid / RLC_MAX_BATCH, nparts = (blockDim.x + RLC_MAX_BATCH - 1) / RLC_MAX_BATCH;
+    const int span = (RLC_MAX_BATCH + nparts - 1) / nparts;
     for (;;) {
         if (need) {
             const Philox4 p = philox4x32_10(key, call, ((unsigned long long)round << 32) | (unsigned int)tid);
             mine = philox_below(p, n);
             out[tid] = mine;
         }
+        if (tid < k) flag[tid] = 0;
         if (tid == 0) *lds_dups = 0;
         __syncthreads();
-        need = false;
-        if (tid < k) {
-            for (int j = 0; j < tid; j++)
-                if (out[j] == mine) { need = true; break; }
-            if (need) atomicAdd(lds_dups, 1);
+        if (t < k) {
+            const long long v = out[t];
+            const int j0 = part * span, j1 = min(t, j0 + span);
+            bool dup = false;
+            for (int j = j0; j < j1; j++) dup |= out[j] == v;
+            if (dup) { flag[t] = 1; *lds_dups = 1; }      // benign races: every writer stores 1
         }
         __syncthreads();
+        need = tid < k && flag[tid] != 0;
         const int dups = *lds_dups;
         __syncthreads();
         if (dups == 0) break;
