@@ -23,6 +23,8 @@
 //
 // Supported shapes: S <= 8, A in {1,2}, H1/HA/HC multiples of 4 in [16,256], B <= 128.
 #pragma once
+#include <type_traits>
+
 #include "rlc_common.h"
 #include "ddpg_rollout_device.h"
 
@@ -37,7 +39,6 @@ constexpr int NT16 = 16;      // N tiles per row at most (N <= 256)
 // Row stride of the byte masks: 272 B = 68 dwords, so that the dword a lane reads in the backward GEMM
 // (row 16mt+c, bytes nc+4g..+3) sits in bank (4c + g + const) mod 64: conflict-free for all 64 lanes.
 constexpr int MSTRIDE = 16 * NT16 + 16;
-constexpr int MC = 7;         // M' tiles per chunk in the weight-gradient GEMMs
 constexpr int SMAX = 8;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
@@ -472,92 +473,149 @@ struct Upd {
     // ---------------------------------------------------------------------------------------
     // weight-gradient GEMM + Adam (+Polyak) epilogue:
     //   G[k'][n] = sum_b X[b][k'] * D[b][n],  X = [hbuf | E] (E = action columns, or none), D as above.
-    // Output rows k' on the MFMA M axis (A operand = hbuf read as columns), cols n owned per wave;
-    // k-dim = batch, lane group g takes b = 16*bt + 4*s + {0,2,1,3}[g] (bank-conflict-free b32 reads).
+    // TRANSPOSED tiles: acc[q][r] = G[k' = 16(m0+q) + c][n = 16t + 4g + r] (D^T on the A side, hbuf on the B
+    // side), so each lane owns 4 CONSECUTIVE n of one weight row = its 16 bytes of block (m0+q, t) of the
+    // tile-blocked arrays: the W / m / v / W' traffic of the Adam epilogue is one 1 KB-contiguous load and one
+    // store per array per tile.  k-dim = batch, lane group g takes b = 4*ks + {0,2,1,3}[g] (conflict-free reads).
+    //
+    // Work items = (N tile t, chunk of <= 4 M' tiles); the 13 x 4 items of a 200 x 200 matrix are dealt
+    // round-robin to the 8 waves (every output tile is independent: no cross-wave reduction), so all four SIMDs
+    // carry the same MFMA load.  While the k-loop of one item runs, the W / m / v / W' of the wave's NEXT item are
+    // already in flight into a second register set.
     // ---------------------------------------------------------------------------------------
+    struct WgPre { f32x4 w[4], m[4], v[4], t[4]; };
+
     template <int NS>
     __device__ __forceinline__ void wgrad_adam(const float* seed /* LDS [MB][NS] */, const float* E /* LDS [MB][AD] or null */,
                                                int Krows /* H1 (+AD if E) */, int N, float* Wp, float* mp, float* vp,
                                                float alpha, float* tapp, float* Wt, float tau) {
+        (void)Krows;
         const int NT = (N + 15) >> 4;
         const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the trunk units; action rows below
+        const int nch = (NMT + 3) >> 2, cbase = NMT / nch, crem = NMT % nch;    // chunk sizes differ by at most one
+        const int nitems = NT * nch;
         const int gperm = ((g & 1) << 1) | (g >> 1);     // 0,2,1,3
-        for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
-            if (t >= NT) break;
+        const int lane4 = (g * 16 + c) << 2;
+
+        auto item_geom = [&](int idx, int& t, int& m0, int& nq) {
+            t = idx % NT;
+            const int ch = idx / NT;
+            nq = cbase + (ch < crem ? 1 : 0);
+            m0 = ch * cbase + (ch < crem ? ch : crem);
+        };
+        // Prefetch an item's W / m / v / W' NOW: their HBM latency hides under the previous item's k-loop
+        // (addresses clamped, stores predicated).
+        auto issue = [&](WgPre& P, int idx) {
+            int t, m0, nq;
+            item_geom(idx, t, m0, nq);
+            const bool n4ok = 16 * t + 4 * g < N;        // N % 4 == 0: all four columns valid or none
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int kp = 16 * (m0 + q) + c;
+                const size_t p = (q < nq && kp < H1 && n4ok) ? ((((size_t)(m0 + q) * NT + t) << 8) + lane4) : 0;
+                P.w[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
+                P.m[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
+                P.v[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
+                P.t[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
+            }
+        };
+        auto run = [&](const WgPre& P, int idx, auto mcc_tag) {
+            constexpr int MCC = decltype(mcc_tag)::value;
+            int t, m0, nq;
+            item_geom(idx, t, m0, nq);
             const int n = 16 * t + c;
-            const bool nok = n < N;
             float wvn[NS];
 #pragma unroll
-            for (int j = 0; j < NS; j++) wvn[j] = nok ? L.wvec[j * 256 + n] : 0.0f;
-            for (int m0 = 0; m0 < NMT; m0 += MC) {
-                // TRANSPOSED tile: acc[q][r] = G[k' = 16(m0+q) + c][n = 16t + 4g + r], i.e. D^T on the A side and
-                // hbuf on the B side, so that each lane owns 4 CONSECUTIVE n of one weight row: the
-                // W / m / v / W' traffic of the Adam epilogue is one 16-byte load + one 16-byte store per array.
-                f32x4 acc[MC];
-                // Prefetch this chunk's W / m / v / W' NOW: their HBM latency hides under the k-loop's MFMAs
-                // instead of serialising in the epilogue (addresses clamped, stores predicated).
-                f32x4 pw_[MC], pm_[MC], pv_[MC], pt_[MC];
-                const int n4 = 16 * t + 4 * g;
-                const bool n4ok = n4 < N;                 // N % 4 == 0: all four columns valid or none
-                sub_begin();
+            for (int j = 0; j < NS; j++) wvn[j] = n < N ? L.wvec[j * 256 + n] : 0.0f;
+            f32x4 acc[MCC];
+            int kq[MCC];
 #pragma unroll
-                for (int q = 0; q < MC; q++) {
-                    acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const int kp = 16 * (m0 + q) + c;
-                    // tile-blocked arrays: block (m0+q, t), this lane's 16 bytes at (g*16+c)*16 -> 1 KB per instruction
-                    const size_t p = (kp < H1 && n4ok) ? ((((size_t)(m0 + q) * NT + t) << 8) + ((g * 16 + c) << 2)) : 0;
-                    pw_[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
-                    pm_[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
-                    pv_[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
-                    pt_[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
-                }
-                sub_stamp(21);
-#pragma unroll 4
-                for (int ks = 0; ks < MT * 4; ks++) {
-                    const int b = 4 * ks + gperm;
-                    // D[b][n] for this lane's (b, n = 16t + c)
-                    float dv = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
-                    const float df = L.mask[b * MSTRIDE + 16 * t + c] ? dv : 0.0f;
-                    // hbuf fragments, unmasked: columns kp >= H1 (last tile only; rows past NMT of the chunk clamp
-                    // to tile 0) only feed accumulator rows that are never stored
-                    float hf[MC];
-#pragma unroll
-                    for (int q = 0; q < MC; q++) {
-                        const int kq = (m0 + q < NMT) ? 16 * (m0 + q) : 0;          // wave-uniform clamp
-                        hf[q] = L.hbuf[b * LDH + kq + c];
-                    }
-#pragma unroll
-                    for (int q = 0; q < MC; q++) acc[q] = mfma16(df, hf[q], acc[q]);
-                }
-                sub_stamp(22);
-#pragma unroll
-                for (int q = 0; q < MC; q++) {
-                    const int kp = 16 * (m0 + q) + c;
-                    f32x4 nw, nm = pm_[q], nv = pv_[q], nt;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        float mm = nm[r], vv = nv[r];
-                        nw[r] = adam_step_fast(pw_[q][r], acc[q][r], mm, vv, alpha);
-                        nm[r] = mm; nv[r] = vv;
-                        nt[r] = pt_[q][r] + tau * (nw[r] - pt_[q][r]);
-                    }
-                    if (kp < H1 && n4ok) {
-                        const size_t p = (((size_t)(m0 + q) * NT + t) << 8) + ((g * 16 + c) << 2);
-                        *reinterpret_cast<f32x4*>(&mp[p]) = nm;
-                        *reinterpret_cast<f32x4*>(&vp[p]) = nv;
-                        *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
-                        *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
-                        if (tapp) *reinterpret_cast<f32x4*>(&tapp[p]) = acc[q];
-                    }
-                }
-                sub_stamp(23);
+            for (int q = 0; q < MCC; q++) {
+                acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                kq[q] = (q < nq ? 16 * (m0 + q) : 0) + c;             // rows past the chunk alias tile 0 (never stored)
             }
+            const unsigned char* mrow = L.mask + 16 * t + c;
             sub_begin();
-            // action rows of the critic's concat (rank-AD term): G[H1+j][n] = sum_b E[b][j] * D[b][n]
-            if (E != nullptr) {
+#pragma unroll 4
+            for (int ks = 0; ks < MT * 4; ks++) {
+                const int b = 4 * ks + gperm;
+                // D[b][n] for this lane's (b, n = 16t + c)
+                float dv = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
+                const float df = mrow[b * MSTRIDE] ? dv : 0.0f;
+                // hbuf fragments, unmasked: columns kp >= H1 (last tile only) only feed rows that are never stored
+                float hf[MCC];
+#pragma unroll
+                for (int q = 0; q < MCC; q++) hf[q] = L.hbuf[b * LDH + kq[q]];
+#pragma unroll
+                for (int q = 0; q < MCC; q++) acc[q] = mfma16(df, hf[q], acc[q]);
+            }
+            sub_stamp(22);
+            const bool n4ok = 16 * t + 4 * g < N;
+#pragma unroll
+            for (int q = 0; q < MCC; q++) {
+                const int kp = 16 * (m0 + q) + c;
+                f32x4 nw, nm = P.m[q], nv = P.v[q], nt;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float mm = nm[r], vv = nv[r];
+                    nw[r] = adam_step_fast(P.w[q][r], acc[q][r], mm, vv, alpha);
+                    nm[r] = mm; nv[r] = vv;
+                    nt[r] = P.t[q][r] + tau * (nw[r] - P.t[q][r]);
+                }
+                if (q < nq && kp < H1 && n4ok) {
+                    const size_t p = (((size_t)(m0 + q) * NT + t) << 8) + lane4;
+                    *reinterpret_cast<f32x4*>(&mp[p]) = nm;
+                    *reinterpret_cast<f32x4*>(&vp[p]) = nv;
+                    *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
+                    *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
+                    if (tapp) *reinterpret_cast<f32x4*>(&tapp[p]) = acc[q];
+                }
+            }
+            sub_stamp(23);
+        };
+        auto run_any = [&](const WgPre& P, int idx) {
+            const int ch = idx / NT;
+            if (cbase + (ch < crem ? 1 : 0) == 4) run(P, idx, std::integral_constant<int, 4>{});
+            else run(P, idx, std::integral_constant<int, 3>{});
+        };
+
+        WgPre PA, PB;
+        int idx = wave;
+        sub_begin();
+        // Compiler-level memory barriers pin the prefetch loads and the epilogue stores where they are written:
+        // without them hipcc reorders the overlapped prefetch across the stores of the previous item / previous
+        // update (K updates in one launch then differ from K launches; tests/test_gpu_ddpg.py pins this).
+#define CBAR() asm volatile("" ::: "memory")
+        CBAR();
+        if (idx < nitems) issue(PA, idx);
+        sub_stamp(21);
+        while (idx < nitems) {
+            CBAR();
+            if (idx + kWaves < nitems) issue(PB, idx + kWaves);
+            CBAR();
+            run_any(PA, idx);
+            CBAR();
+            idx += kWaves;
+            if (idx >= nitems) break;
+            if (idx + kWaves < nitems) issue(PA, idx + kWaves);
+            CBAR();
+            run_any(PB, idx);
+            CBAR();
+            idx += kWaves;
+        }
+#undef CBAR
+        sub_begin();
+        // action rows of the critic's concat (rank-AD term): G[H1+j][n] = sum_b E[b][j] * D[b][n]; one N tile per
+        // wave at a time
+        if (E != nullptr) {
+            for (int t = wave; t < NT; t += kWaves) {
+                const int n = 16 * t + c;
+                const bool nok = n < N;
+                float wvn[NS];
+#pragma unroll
+                for (int j = 0; j < NS; j++) wvn[j] = nok ? L.wvec[j * 256 + n] : 0.0f;
                 float ge[AD];
 #pragma unroll
                 for (int j = 0; j < AD; j++) ge[j] = 0.0f;
@@ -584,8 +642,8 @@ struct Upd {
                     }
                 }
             }
-            sub_stamp(24);
         }
+        sub_stamp(24);
     }
 };
 
