@@ -19,7 +19,7 @@ MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]
 FAST = os.environ.get("RLC_FAST_BUILD", "0") == "1"     # developer loop: only the headline shape
 if FAST:
     MFMA_VARIANTS = [(7, 1)]
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + (["-DRLC_STAMPS"] if STAMPS else [])
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-Wno-unused-result"] + (["-DRLC_STAMPS"] if STAMPS else [])
 if os.environ.get("RLC_FAST_BUILD", "0") == "1":
     CFLAGS.append("-DRLC_ONLY_7_1")
 

@@ -144,24 +144,31 @@ struct Upd {
     // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
     // ---------------------------------------------------------------------------------------
     __device__ __forceinline__ void trunk(const float* W1, const float* b1, const float* xs) {
+        if (S <= 4) trunk_t<4>(W1, b1, xs);      // wave-uniform: Pendulum-sized states need one 16-byte read per row
+        else trunk_t<SMAX>(W1, b1, xs);
+    }
+    template <int SP>
+    __device__ __forceinline__ void trunk_t(const float* W1, const float* b1, const float* xs) {
         // 256 column slots x 2 row halves
         const int half = tid >> 8;
         for (int k = tid & 255; k < LDH; k += 256) {
-            float w[SMAX];
+            float w[SP];
             float bias = 0.0f;
             const bool live = k < H1;
 #pragma unroll
-            for (int i = 0; i < SMAX; i++) w[i] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
+            for (int i = 0; i < SP; i++) w[i] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
             if (live) bias = b1[k];
 #pragma unroll 4
             for (int b = half * (MB / 2); b < (half + 1) * (MB / 2); b++) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(&xs[b * SMAX]);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(&xs[b * SMAX + 4]);
                 float acc = 0.0f;      // same i-order as the scalar form; padded lanes multiply by w = 0
 #pragma unroll
                 for (int i = 0; i < 4; i++) acc += x0[i] * w[i];
+                if (SP > 4) {
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&xs[b * SMAX + 4]);
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc += x1[i] * w[4 + i];
+                    for (int i = 0; i < 4; i++) acc += x1[i] * w[(SP > 4 ? 4 : 0) + i];
+                }
                 acc = fmaxf(acc + bias, 0.0f);
                 L.hbuf[b * LDH + k] = (live && b < B) ? acc : 0.0f;
             }
@@ -425,6 +432,12 @@ struct Upd {
     // trunk units and apply Adam (+ optional Polyak) right here.
     __device__ __forceinline__ void trunk_grad_adam(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
                                                     float alpha, int oW1, int ob1, float* tap, float* tt, float tau) {
+        if (S <= 4) trunk_grad_adam_t<4>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau);     // wave-uniform
+        else trunk_grad_adam_t<SMAX>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau);
+    }
+    template <int SP>
+    __device__ __forceinline__ void trunk_grad_adam_t(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
+                                                      float alpha, int oW1, int ob1, float* tap, float* tt, float tau) {
         const int NT = (H1 + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
@@ -432,9 +445,9 @@ struct Upd {
             if (t >= NT) continue;
             const int k = 16 * t + c;
             float gb = 0.0f;
-            float gw[SMAX];
+            float gw[SP];
 #pragma unroll
-            for (int s = 0; s < SMAX; s++) gw[s] = 0.0f;
+            for (int s = 0; s < SP; s++) gw[s] = 0.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -444,20 +457,24 @@ struct Upd {
                     const float d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] : 0.0f;
                     gb += d;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(&L.x[b * SMAX]);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(&L.x[b * SMAX + 4]);
 #pragma unroll
-                    for (int s = 0; s < 4; s++) { gw[s] += x0[s] * d; gw[4 + s] += x1[s] * d; }
+                    for (int s = 0; s < 4; s++) gw[s] += x0[s] * d;
+                    if (SP > 4) {
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(&L.x[b * SMAX + 4]);
+#pragma unroll
+                        for (int s = 0; s < 4; s++) gw[(SP > 4 ? 4 : 0) + s] += x1[s] * d;
+                    }
                 }
             gb = col4_sum(gb);
 #pragma unroll
-            for (int s = 0; s < SMAX; s++) gw[s] = col4_sum(gw[s]);
+            for (int s = 0; s < SP; s++) gw[s] = col4_sum(gw[s]);
             // lanes g == s' handle row s' (spread the Adam work over the 4 lane groups)
             if (k < H1) {
                 for (int s = g; s <= S; s += 4) {
                     const bool is_bias = s == S;
                     float gr = gb;
 #pragma unroll
-                    for (int q = 0; q < SMAX; q++)
+                    for (int q = 0; q < SP; q++)
                         if (q == s && !is_bias) gr = gw[q];
                     const int p = is_bias ? ob1 + k : oW1 + s * H1 + k;
                     float mm = m[p], vv = v[p];
