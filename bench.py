@@ -85,6 +85,23 @@ def cpu_baseline(seconds=15.0, records=200000):
                       "structured host loop; TF-1.15 itself cannot run here" % (n, dt, records)}
 
 
+def pmc_traffic(n_agents, updates_per_launch, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, scripts/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for 16 B/lane streams -> an upper bound, the dword-load share being uncalibrated).  Counters cannot be read
+    inside a timed run, so this is the measurement of the same command line taken when the kernel last changed;
+    null when the configuration differs from the measured one."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            m = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if kernel != "mfma" or m.get("agents") != n_agents or m.get("updates_per_launch") != updates_per_launch:
+        return None
+    return m.get("traffic_bytes_per_launch_upper")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +178,7 @@ def main():
     kernel = pop.kernel_in_use()
 
     if rank == 0:
+        traffic = pmc_traffic(NA, U, kernel)
         updates_per_launch = NA * U
         launch_s = ev_ms * 1e-3 / args.steps
         ach_flops = FLOP_PER_UPDATE * updates_per_launch / launch_s
@@ -179,10 +197,10 @@ def main():
                        "per_gpu_value": NA * U * args.steps / dt_max,
                        "parallelism": "independent seeds x%d per GPU, x%d GPUs" % (NA, world)},
             "roofline": {"bound": "mfma", "achieved": ach_flops / 1e12, "peak": PEAK_FP32_MATRIX / 1e12,
-                         "unit": "TFLOP/s", "frac": ach_flops / PEAK_FP32_MATRIX, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach_flops / PEAK_FP32_MATRIX, "traffic": traffic,
                          "kernel_ms_per_launch": launch_s * 1e3, "flop_per_update": FLOP_PER_UPDATE},
             "roofline_hbm": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                             "frac": ach_bytes / PEAK_HBM, "traffic": None, "bytes_per_update": BYTES_PER_UPDATE},
+                             "frac": ach_bytes / PEAK_HBM, "traffic": traffic, "bytes_per_update": BYTES_PER_UPDATE},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
