@@ -177,3 +177,28 @@ def test_main_device_rollout_pickle(hip_lib, tmp_path):
     assert set(run) == {"random_seed", "total_timesteps", "eval_interval_timesteps", "episodes_per_eval",
                         "eval_episode_rewards", "eval_episode_steps", "timesteps_at_eval", "train_episode_steps",
                         "train_episode_rewards", "total_train_episodes", "eval_time", "train_time"}
+
+
+def test_rollout_ring_eviction_matches_fifo(hip_lib):
+    """Replay capacity smaller than the run: the device ring evicts the oldest transition exactly like the
+    reference's RandomAccessQueue (utils/custom_collections.py:83-101); logical order = insertion order."""
+    from oracle.ddpg import Dims
+    from oracle.rollout import RolloutOracle
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    dims, B, cap = (3, 1, 32, 32, 32), 16, 64
+    pop, thetas = _pop(dims, B, 1, [1e-3], [1e-2], [99], "generic", cap=cap)
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00015, "EpisodeSteps": 40,
+           "EvalIntervalMilSteps": 0.0001, "EvalEpisodes": 1}
+    DeviceExperiment(pop, env).run()
+    orc = RolloutOracle(Dims(*dims), thetas[0], 1e-3, 1e-2, 0.01, SMIN, SMAX, AMIN, AMAX, 99, B, cap, 0.99, 0, 40, 150,
+                        100, 1).run()
+    assert pop.replay_size(0) == len(orc.replay) == cap
+    s, act, r, s2, g = pop.replay_gather(0, np.arange(cap))
+    assert np.allclose(s, np.array([t[0] for t in orc.replay]), atol=5e-3)
+    assert np.allclose(act, np.array([t[1] for t in orc.replay]), atol=5e-3)
+    # structure independent of float drift: consecutive transitions chain except over the episode boundaries
+    same = np.all(s2[:-1] == s[1:], axis=1)
+    osame = np.array([np.array_equal(orc.replay[i][3], orc.replay[i + 1][0]) for i in range(cap - 1)])
+    assert np.array_equal(same, osame)
+    with pytest.raises(Exception):
+        pop.replay_gather(0, [cap])          # index out of range (custom_collections.py:48,58)
