@@ -14,6 +14,10 @@ and ``--gpu`` picks the HIP device.
 ``--device_rollout`` runs ALL indices of the range concurrently as one population on the GPU with the
 environment simulated on the device (rlcontrol_amd/device_experiment.py; DDPG on Pendulum-v0): same
 schedule, same pickle, Philox random streams instead of numpy's.
+
+Under ``python -m torch.distributed.run --nproc-per-node N main.py ...`` the INDEX range is dealt round-robin to
+the N ranks (one GPU each, nothing exchanged while training); one all-gather of the run records at the end
+(RCCL on GPUs, rlcontrol_amd/sweep.py) and rank 0 writes the single pickle.
 """
 import argparse
 import json
@@ -177,6 +181,10 @@ def main(argv=None):
     data = new_data_dict(agent_json, env_json)
     save_dir = args.save_dir + "/" + env_name + "_" + agent_name + 'results/'
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        return main_distributed(args, agent_json, env_json, train_env, test_env, env_params, arg_params, save_dir)
+
     if args.device_rollout:
         run_indices_on_device(list(range(args.indices[0], args.indices[2], args.indices[1])), agent_json, env_json,
                               env_params, arg_params, data, verbose=not args.quiet)
@@ -192,6 +200,71 @@ def main(argv=None):
         save_file = save_dir + "data_%d_%d_%d.pkl" % tuple(args.indices)
         with open(save_file, "wb") as out_file:
             pickle.dump(data, out_file)
+    return data
+
+
+def main_distributed(args, agent_json, env_json, train_env, test_env, env_params, arg_params, save_dir):
+    """One process per GPU: this rank's shard of the INDEX range, then ONE all-gather of the run records."""
+    import torch
+    import torch.distributed as dist
+    from rlcontrol_amd import sweep
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    on_gpu = torch.cuda.is_available()
+    device = None
+    if on_gpu:
+        torch.cuda.set_device(args.gpu)
+        device = torch.device("cuda", args.gpu)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl" if on_gpu else "gloo", **({"device_id": device} if on_gpu else {}))
+    mine = sweep.rank_indices(args.indices[0], args.indices[1], args.indices[2], rank, world)
+    local = new_data_dict(agent_json, env_json)
+    verbose = (not args.quiet) and rank == 0
+    if args.device_rollout:
+        if mine:
+            run_indices_on_device(mine, agent_json, env_json, env_params, arg_params, local, verbose=verbose)
+    else:
+        for index in mine:
+            run_index(index, agent_json, env_json, train_env, test_env, env_params, arg_params, local, verbose=verbose)
+    # local runs in index order (each setting's list is in increasing index = increasing seed)
+    n_settings = get_sweep_parameters(agent_json['sweeps'], 0)[1]
+    runs = {}
+    for sweep_id, sd in local["experiment_data"].items():
+        for rd in sd["runs"]:
+            runs[rd["random_seed"] * n_settings + sweep_id] = rd
+    total = int(env_json["TotalMilSteps"] * 1000000)
+    interval = int(env_json["EvalIntervalMilSteps"] * 1000000)
+    eval_shape = (total // interval + 1, int(env_json["EvalEpisodes"]))
+    max_tr = sweep.all_reduce_max(max([len(r["train_episode_rewards"]) for r in runs.values()] + [1]), device)
+    vlen = sweep.full_vec_len(eval_shape, max_tr)
+    vecs = [sweep.pack_full_run(i, runs[i], eval_shape, max_tr) for i in sorted(runs)]
+    n_all = len(range(args.indices[0], args.indices[2], args.indices[1]))
+    gathered = sweep.all_gather_runs(vecs, (n_all + world - 1) // world, vlen, device)
+    data = new_data_dict(agent_json, env_json)
+    if rank == 0:
+        got = {}
+        for row in gathered:
+            if not np.isnan(row[0]):
+                idx, fields = sweep.unpack_full_run(row, eval_shape, max_tr)
+                got[idx] = fields
+        for index in range(args.indices[0], args.indices[2], args.indices[1]):
+            agent_params, _ = get_sweep_parameters(agent_json['sweeps'], index)
+            sweep_id = index % n_settings
+            if sweep_id not in data["experiment_data"]:
+                data["experiment_data"][sweep_id] = {"agent_params": dict(agent_params), "runs": []}
+            f = got[index]
+            rd = {"random_seed": f["random_seed"], "total_timesteps": env_json["TotalMilSteps"] * 1000000,
+                  "eval_interval_timesteps": env_json["EvalIntervalMilSteps"] * 1000000,
+                  "episodes_per_eval": env_json["EvalEpisodes"],
+                  "eval_episode_rewards": f["eval_episode_rewards"], "eval_episode_steps": f["eval_episode_steps"],
+                  "timesteps_at_eval": np.arange(f["eval_episode_rewards"].shape[0]) * interval,
+                  "train_episode_steps": f["train_episode_steps"], "train_episode_rewards": f["train_episode_rewards"],
+                  "total_train_episodes": f["total_train_episodes"], "eval_time": f["eval_time"],
+                  "train_time": f["train_time"]}
+            data["experiment_data"][sweep_id]["runs"].append(rd)
+        os.makedirs(save_dir, exist_ok=True)
+        with open(save_dir + "data_%d_%d_%d.pkl" % tuple(args.indices), "wb") as out_file:
+            pickle.dump(data, out_file)
+    dist.barrier()
     return data
 
 

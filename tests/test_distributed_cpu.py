@@ -64,3 +64,78 @@ def test_rank_indices_cover_the_range_without_overlap():
         parts = [sweep.rank_indices(3, 7, 200, r, world) for r in range(world)]
         flat = sorted(i for p in parts for i in p)
         assert flat == list(range(3, 200, 7))
+
+
+# ---- the driver itself under two ranks (gloo): shards, one all-gather, rank 0 writes the complete pickle --------
+ENV2 = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00025, "EpisodeSteps": 100,
+        "EvalIntervalMilSteps": 0.0001, "EvalEpisodes": 2}
+
+
+class _FakeAgent(object):
+    def __init__(self, config):
+        self.bias = config.actor_lr * 100 + config.random_seed
+
+    def start(self, s, is_train):
+        return np.array([min(self.bias, 2.0)])
+
+    step = start
+
+    def update(self, *a):
+        pass
+
+    def reset(self):
+        pass
+
+
+def _main_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    import main as drv
+    drv.create_agent = lambda name, cfg: _FakeAgent(cfg)
+    envf = os.path.join(tmp, "Pendulum-v0.json")
+    if rank == 0:
+        with open(envf, "w") as f:
+            json.dump(ENV2, f)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    drv.main(["--env_json", envf, "--agent_json", os.path.join(ROOT, "jsonfiles/agent/ddpg.json"),
+              "--indices", "0", "7", "70", "--save_dir", os.path.join(tmp, "res"), "--quiet"])
+    dist.destroy_process_group()
+
+
+def test_main_under_two_ranks_writes_one_complete_pickle(tmp_path):
+    import pickle
+    ctx = mp.get_context("spawn")
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_main_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    with open(tmp_path / "res" / "Pendulum-v0_ddpgresults" / "data_0_7_70.pkl", "rb") as f:
+        multi = pickle.load(f)
+    # the same sweep in one process
+    sys.path.insert(0, ROOT)
+    import json
+    import main as drv
+    old = drv.create_agent
+    drv.create_agent = lambda name, cfg: _FakeAgent(cfg)
+    try:
+        envf = tmp_path / "Pendulum-v0.json"
+        single = drv.main(["--env_json", str(envf), "--agent_json", os.path.join(ROOT, "jsonfiles/agent/ddpg.json"),
+                           "--indices", "0", "7", "70", "--save_dir", str(tmp_path / "one"), "--quiet"])
+    finally:
+        drv.create_agent = old
+    assert sorted(multi["experiment_data"]) == sorted(single["experiment_data"])
+    for sid in single["experiment_data"]:
+        a, b = multi["experiment_data"][sid], single["experiment_data"][sid]
+        assert a["agent_params"]["actor_lr"] == b["agent_params"]["actor_lr"]
+        assert [r["random_seed"] for r in a["runs"]] == [r["random_seed"] for r in b["runs"]]
+        for ra, rb in zip(a["runs"], b["runs"]):
+            for k in ("eval_episode_rewards", "eval_episode_steps", "timesteps_at_eval", "train_episode_steps",
+                      "train_episode_rewards"):
+                assert np.array_equal(np.asarray(ra[k]), np.asarray(rb[k])), k
+            assert ra["total_train_episodes"] == rb["total_train_episodes"]
