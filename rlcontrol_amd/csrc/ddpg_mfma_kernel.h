@@ -859,15 +859,11 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         u.template bwd_gemm<1>(acc, th + d.oWc2, HC, H1, L.dq);
         __syncthreads();      // every wave has finished reading the pre-step Wc2 rows and W1
         STAMP();
-#ifndef RLC_EXP_NOTRUNKG
         u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f);
         STAMP();
-#endif
         // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue
-#ifndef RLC_EXP_NOWGRAD
         u.template wgrad_adam<1>(L.dq, L.a, H1 + AD, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
                      tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau);
-#endif
         // small critic tensors: Wc3, bc2 (column owners), bc3 (one thread)
         {
             const int NT = (HC + 15) >> 4;
@@ -936,9 +932,6 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int i = 0; i < NTW; i++) h2acc[mt][i] = acc[mt][i];
-#ifdef RLC_EXP_NOPARK
-#define h2acc acc
-#endif
 
         // ================= step 5: dQ/da at the scaled action, updated critic (DDPG.py:91) =================
         u.fwd_gemm(acc, th + d.oWc2, HC, H1);
@@ -994,14 +987,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         u.template bwd_gemm<AD>(acc, th + d.oWa2, HA, H1, L.dz);
         __syncthreads();
         STAMP();
-#ifndef RLC_EXP_NOTRUNKG
         u.trunk_grad_adam(acc, th, m_a, v_a, alpha_a, d.oW1, d.ob1, tap_ga, tt, tau);
         STAMP();
-#endif
-#ifndef RLC_EXP_NOWGRAD
         u.template wgrad_adam<AD>(L.dz, nullptr, H1, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
                      tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau);
-#endif
         {
             const int NT = (HA + 15) >> 4;
 #pragma unroll

@@ -292,3 +292,37 @@ def test_device_ou_noise_statistics(hip_lib):
     one = pop.act(st, explore=True) - greedy           # first draw after reset: N(0, sigma)
     assert abs(one.std() - 0.2) < 0.08
     pop.close()
+
+
+@pytest.mark.parametrize("dims,B", [((3, 1, 200, 200, 200), 100), ((8, 2, 64, 48, 40), 17), ((5, 2, 200, 120, 56), 32)])
+def test_weight_layout_round_trip_across_kernel_switch(hip_lib, dims, B):
+    """The tile-blocked device layout of Wa2 / Wc2 (MFMA kernel) is private to the library: the ABI blob is
+    row-major under either kernel, survives switching the kernel (re-pack on the host), and both kernels compute
+    the same update from it."""
+    from oracle.ddpg import Dims, init_params
+    pop, smin, smax, amax = _make(dims, B)
+    _skip_unless_supported(pop, "mfma")
+    th = init_params(Dims(*dims), 9)
+    pop.set_params(0, th)
+    rng = np.random.RandomState(2)
+    m = rng.randn(th.size).astype(np.float32)
+    pop.set_blob(0, "critic_m", m)
+    assert np.array_equal(pop.get_blob(0, "theta"), th) and np.array_equal(pop.get_blob(0, "theta_target"), th)
+    pop.set_kernel("generic")                      # blocked -> row-major
+    assert pop.kernel_in_use() == "generic"
+    assert np.array_equal(pop.get_blob(0, "theta"), th) and np.array_equal(pop.get_blob(0, "critic_m"), m)
+    s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+    pop.set_blob(0, "critic_m", np.zeros_like(m))
+    pop.update_batch(0, s, a, s2, r, g)
+    after_generic = pop.get_blob(0, "theta")
+    pop.set_kernel("mfma")                         # row-major -> blocked, optimizer state included
+    assert np.array_equal(pop.get_blob(0, "theta"), after_generic)
+    pop2, _, _, _ = _make(dims, B)
+    pop2.set_kernel("mfma")
+    pop2.set_params(0, th)
+    pop2.update_batch(0, s, a, s2, r, g)
+    assert _rel(pop2.get_blob(0, "theta_target"), pop.get_blob(0, "theta_target")) < 1e-6
+    pop.update_batch(0, s, a, s2, r, g)            # second update under the MFMA kernel from the re-packed state
+    pop2.update_batch(0, s, a, s2, r, g)
+    assert _rel(pop2.get_blob(0, "critic_v"), pop.get_blob(0, "critic_v")) < 1e-4
+    assert _rel(pop2.get_blob(0, "theta_target"), pop.get_blob(0, "theta_target")) < 1e-5
