@@ -57,9 +57,9 @@ def synthetic_pendulum_replay(n, seed=0):
             np.full(n, 0.99, np.float64))
 
 
-def cpu_baseline(seconds=15.0, records=200000):
-    """Reference-structured CPU port on a bounded sample (1 core): list-of-records replay + sample_n_k +
-    5 np.array conversions + float64 TD glue + the C restatement of the 7-step update."""
+def _cpu_port_run(seconds, records):
+    """Reference-structured CPU port on a bounded sample (one core): list-of-records replay + sample_n_k +
+    5 np.array conversions + float64 TD glue + the C restatement of the 7-step update.  Returns (updates, s)."""
     from oracle.cpu_baseline import ListReplay, Transition
     from oracle.ddpg import DDPGOracle, Dims, init_params
     try:
@@ -79,10 +79,35 @@ def cpu_baseline(seconds=15.0, records=200000):
         (bs, ba, br, bs2, bg), _ = rep.sample_batch(B)
         net.update(bs, ba, bs2, br, bg)
         n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "gradient updates/s", "cores": 1, "kind": "port",
-            "sample": "%d updates (%.1f s) on a %d-record list replay; oracle/ddpg_oracle.c + reference-"
-                      "structured host loop; TF-1.15 itself cannot run here" % (n, dt, records)}
+    return n, time.perf_counter() - t0
+
+
+def cpu_baseline(seconds=15.0, records=200000, all_cores=True):
+    """The CPU baseline beside the GPU number: (i) one core = the reference's own deployment unit
+    (one INDEX per process), the primary figure; (ii) one independent process per host core (one INDEX each).
+    Runs BEFORE anything touches the GPU: the workers of (ii) are child processes."""
+    n, dt = _cpu_port_run(seconds, records)
+    out = {"value": n / dt, "unit": "gradient updates/s", "cores": 1, "kind": "port",
+           "sample": "%d updates (%.1f s) on a %d-record list replay; oracle/ddpg_oracle.c + reference-"
+                     "structured host loop; TF-1.15 itself cannot run here" % (n, dt, records)}
+    if all_cores:
+        import subprocess
+        cores = max(1, min(len(os.sched_getaffinity(0)), 16))     # a one-GPU box's CPU share is 16 cores
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-seconds", str(seconds),
+               "--cpu-records", str(records)]
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+        rates = []
+        deadline = time.time() + seconds + 120.0
+        for pr in procs:
+            try:
+                o, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+                k, t = o.split()[-2:]
+                rates.append(float(k) / float(t))
+            except Exception:           # a worker that failed or overran is killed; the one-core figure stands
+                pr.kill()
+        out["all_cores"] = {"value": sum(rates) if rates else None, "cores": len(rates),
+                            "sample": "%d independent processes (one INDEX each), %.0f s each" % (len(rates), seconds)}
+    return out
 
 
 def pmc_traffic(n_agents, updates_per_launch, kernel):
@@ -112,10 +137,23 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-records", type=int, default=200000)
+    ap.add_argument("--cpu-worker", action="store_true", help="internal: one process of the all-cores CPU baseline")
     args = ap.parse_args()
+    if args.cpu_worker:
+        n, dt = _cpu_port_run(args.cpu_seconds, args.cpu_records)
+        print(n, dt)
+        return
+
+    rank = int(os.environ.get("RANK", "0"))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_base = None
+    if rank == 0 and world_env == 1 and not args.no_cpu_baseline:
+        from __graft_entry__ import build_oracle
+        build_oracle()
+        cpu_base = cpu_baseline(args.cpu_seconds, args.cpu_records)   # before the GPU is initialised (child processes)
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
@@ -202,10 +240,7 @@ def main():
             "roofline_hbm": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                              "frac": ach_bytes / PEAK_HBM, "traffic": traffic, "bytes_per_update": BYTES_PER_UPDATE},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     pop.close()
     if dist is not None:
