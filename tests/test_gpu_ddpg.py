@@ -326,3 +326,32 @@ def test_weight_layout_round_trip_across_kernel_switch(hip_lib, dims, B):
     pop2.update_batch(0, s, a, s2, r, g)
     assert _rel(pop2.get_blob(0, "critic_v"), pop.get_blob(0, "critic_v")) < 1e-4
     assert _rel(pop2.get_blob(0, "theta_target"), pop.get_blob(0, "theta_target")) < 1e-5
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_device_sampler_updates_equal_oracle_on_the_same_philox_minibatches(hip_lib, kernel):
+    """The fully fused path (device sampler -> gather -> update, K updates in one launch) against the oracle fed
+    with the minibatches oracle/philox.py draws from the same (seed, call) stream: the indices are bit-identical
+    (tests/test_gpu_rollout.py), so the weights after K updates must agree like any other update parity."""
+    from oracle import philox
+    from oracle.ddpg import Dims, init_params
+    from oracle.cpu_baseline import synthetic_pendulum_replay
+    dims, B, N, K, seed = (3, 1, 200, 200, 200), 100, 5000, 6, 424242
+    pop, smin, smax, amax = _make(dims, B, cap=N, seeds=[seed], smin=np.array(SMIN, float), smax=np.array(SMAX, float),
+                                  amax=AMAX)
+    _skip_unless_supported(pop, kernel)
+    th = init_params(Dims(*dims), 2)
+    pop.set_params(0, th)
+    s, a, r, s2, g = synthetic_pendulum_replay(N, 0)
+    pop.replay_add_batch(0, s, a, r, s2, g)
+    o = _oracle(dims, th, (1e-3, 1e-2), smin, smax, amax)
+    pop.update(K)
+    for call in range(K):
+        i = philox.sample_distinct(N, B, seed, call)
+        taps = o.update(s[i], a[i], s2[i], r[i], g[i], taps=True)
+    assert _rel(pop.last_tap(0, "q"), taps["q"]) < 1e-4            # q of the K-th minibatch after K-1 shared updates
+    dev, orc = pop.named(pop.get_blob(0, "theta_target")), pop.named(o.theta_t)
+    for name in dev:
+        assert _rel(dev[name], orc[name]) < 2e-4, name
+    assert np.allclose(pop.get_beta_powers(0), o.pw, rtol=1e-6)
+    pop.close()
