@@ -151,3 +151,30 @@ def test_naf_hip_replay_path_act_and_agent(hip_lib):
         assert a.shape == (1,) and abs(a[0]) <= 2.0
     assert agent.replay_buffer.get_size() == 60
     assert np.array_equal(agent.start(obs, False), agent.start(obs, False))
+
+
+@pytest.mark.gpu
+def test_naf_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib):
+    """Fused path with the DEVICE sampler: same Philox stream as oracle/philox.py, so K updates in one launch
+    must match the oracle fed with the minibatches that stream selects."""
+    from oracle import philox
+    dims, B, N, K = (8, 2, 200, 200), 64, 2048, 4
+    d = NafDims(*dims)
+    smin, smax, amax = _bounds(*dims[:2])
+    pop = _pop(dims, B, cap=N, lr=1e-4)        # seeds = [3]
+    th = init_params(d, 17)
+    rng = np.random.RandomState(6)
+    s, a, s2 = rng.uniform(-3, 3, (N, 8)), rng.uniform(-1, 1, (N, 2)), rng.uniform(-3, 3, (N, 8))
+    r, g = rng.uniform(-1, 1, N), np.where(rng.rand(N) < 0.1, 0.0, 0.99)
+    pop.set_params(0, th)
+    pop.replay_add_batch(0, s, a, r, s2, g)
+    o = NAFOracle(d, th, 1e-4, 0.01, smin, smax, amax)
+    pop.update(K)
+    s32, a32, s232 = s.astype(np.float32), a.astype(np.float32), s2.astype(np.float32)
+    for call in range(K):
+        j = philox.sample_distinct(N, B, 3, call)
+        t = o.update(s32[j], a32[j], s232[j], r[j], g[j], taps=True)
+    for k in ("q", "y", "V"):
+        assert _rel(pop.last_tap(0, k), t[k]) < 1e-4, k
+    assert _rel(pop.get_blob(0, "theta_target"), o.theta_t) < 1e-4
+    pop.close()

@@ -192,3 +192,28 @@ def test_sac_dropin_agent_runs_on_pendulum(hip_lib):
     assert agent.replay_buffer.get_size() == 80
     g1, g2 = agent.start(obs, False), agent.start(obs, False)
     assert np.array_equal(g1, g2)                    # evaluation uses the mean action
+
+
+@pytest.mark.gpu
+def test_sac_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib):
+    """Fused path with the DEVICE sampler (host eps): the indices come from the Philox stream that
+    oracle/philox.py restates bit for bit, so K updates in one launch must match the oracle fed with them."""
+    from oracle import philox
+    from oracle.cpu_baseline import synthetic_pendulum_replay
+    dims, B, N, K = (3, 1, 128, 128, 128, 128), 32, 2048, 4
+    d = SacDims(*dims)
+    pop = _pop(dims, B, cap=N)                 # seeds = [5]
+    th = _benign(d, init_params(d, 21))
+    s, a, r, s2, g = synthetic_pendulum_replay(N, 0)
+    pop.set_params(0, th)
+    pop.replay_add_batch(0, s, a, r, s2, g)
+    o = SACOracle(d, th, 1e-2, 1e-1, 0.5, 0.01, -1.0, 1.0, 2.0)
+    eps = np.random.RandomState(3).randn(1, K, B, 1)
+    pop.update(K, eps=eps)
+    for call in range(K):
+        j = philox.sample_distinct(N, B, 5, call)
+        t = o.update(s[j], a[j], s2[j], r[j], g[j], eps[0, call], taps=True)
+    for k in ("q", "v", "q_pi"):
+        assert _rel(pop.last_tap(0, k), t[k]) < 1e-4, k
+    assert _rel(pop.get_blob(0, "theta_target"), o.theta_t) < 1e-4
+    pop.close()
