@@ -9,11 +9,111 @@ namespace gen {
 constexpr int kThreads = 256;
 constexpr int kRows = 4;   // batch rows per thread-item in the dense loops
 
+typedef float gf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
+
+// ---- 4 x 4 register-tile fast paths (taken when shapes are multiples of 4 and the operands 16-byte aligned;
+// the element-wise summation order over the contraction index is the same as in the scalar loops below) ----
+
+// Y[b0..+3][n0..+3]: per 4 k one 16-byte read per row of X (wave-uniform) and per row of W (coalesced over n)
+__device__ inline void blk_dense_tile4(const float* X, int ldx, int K, const float* E, int Ke, const float* W,
+                                       const float* bias, int N, float* Y, int ldy, int B, int act) {
+    const int rb = (B + 3) >> 2, nb = N >> 2, K4 = K & ~3;
+    for (int it = threadIdx.x; it < rb * nb; it += kThreads) {
+        const int n0 = (it % nb) << 2;
+        const int b0 = (it / nb) << 2;
+        int br[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) br[j] = min(b0 + j, B - 1);
+        gf4 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[j] = gf4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K4; k += 4) {
+            gf4 x[4], w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) x[j] = *reinterpret_cast<const gf4*>(&X[(size_t)br[j] * ldx + k]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = *reinterpret_cast<const gf4*>(&W[(size_t)(k + i) * N + n0]);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] += x[j][i] * w[i];
+        }
+        for (int k = K4; k < K; k++) {
+            const gf4 w = *reinterpret_cast<const gf4*>(&W[(size_t)k * N + n0]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] += X[(size_t)br[j] * ldx + k] * w;
+        }
+        for (int e = 0; e < Ke; e++) {
+            const gf4 w = *reinterpret_cast<const gf4*>(&W[(size_t)(K + e) * N + n0]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] += E[br[j] * Ke + e] * w;
+        }
+        const gf4 bs = *reinterpret_cast<const gf4*>(&bias[n0]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (b0 + j < B) {
+                gf4 v = acc[j] + bs;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (act == 1) v[c] = fmaxf(v[c], 0.0f);
+                    else if (act == 2) v[c] = tanhf(v[c]);
+                    Y[(size_t)(b0 + j) * ldy + n0 + c] = v[c];
+                }
+            }
+        }
+    }
+}
+
+// dX[b0..+3][k0..+3] = sum_n dY[b][n] W[k][n]: per 4 n one 16-byte read per row of dY and per row of W
+__device__ inline void blk_bwd_input_tile4(const float* dY, int lddy, int N, const float* W, const float* Hk, int K,
+                                           float* dX, int B, bool accumulate) {
+    const int rb = (B + 3) >> 2, kb = K >> 2;
+    for (int it = threadIdx.x; it < rb * kb; it += kThreads) {
+        const int k0 = (it % kb) << 2;
+        const int b0 = (it / kb) << 2;
+        int br[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) br[j] = min(b0 + j, B - 1);
+        float acc[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[j][i] = 0.0f;
+        for (int n = 0; n < N; n += 4) {
+            gf4 d[4], w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[j] = *reinterpret_cast<const gf4*>(&dY[(size_t)br[j] * lddy + n]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = *reinterpret_cast<const gf4*>(&W[(size_t)(k0 + i) * N + n]);
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[j][i] += d[j][c] * w[i][c];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (b0 + j < B)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const size_t p = (size_t)(b0 + j) * K + k0 + i;
+                    const float v = (Hk == nullptr || Hk[p] > 0.0f) ? acc[j][i] : 0.0f;
+                    dX[p] = accumulate ? dX[p] + v : v;
+                }
+    }
+}
+
 // Y[b,n] = act( sum_k X[b,k] W[k,n] + sum_j E[b,j] W[K+j,n] + bias[n] );  act: 0 none, 1 relu, 2 tanh
 // X: [B,K] row-major (ldx); E: optional extra input columns (the action, concatenated LAST:
 // hydra_ddpg_network.py:128).  Lanes run over n (coalesced W rows); X/E reads are wave-uniform.
 __device__ inline void blk_dense(const float* X, int ldx, int K, const float* E, int Ke, const float* W,
                           const float* bias, int N, float* Y, int ldy, int B, int act) {
+    if ((N & 3) == 0 && (ldx & 3) == 0 && K >= 4 && al16(X) && al16(W) && al16(bias)) {
+        blk_dense_tile4(X, ldx, K, E, Ke, W, bias, N, Y, ldy, B, act);
+        return;
+    }
     const int rb = (B + kRows - 1) / kRows;
     for (int it = threadIdx.x; it < rb * N; it += kThreads) {
         const int n = it % N;
@@ -53,6 +153,11 @@ __device__ inline void blk_dense(const float* X, int ldx, int K, const float* E,
 // dX[b,k] = (Hk[b,k] > 0) ? sum_n dY[b,n] W[k,n] : 0      (W[k][n] rows k < K only)
 __device__ inline void blk_dense_bwd_input(const float* dY, int N, const float* W, const float* Hk, int K, float* dX,
                                     int B) {
+    if ((N & 3) == 0 && (K & 3) == 0 && al16(dY) && al16(W)) {
+        // this variant always masks by Hk > 0 (Hk is never null here)
+        blk_bwd_input_tile4(dY, N, N, W, Hk, K, dX, B, false);
+        return;
+    }
     const int rb = (B + kRows - 1) / kRows;
     for (int it = threadIdx.x; it < rb * K; it += kThreads) {
         const int k = it % K;
@@ -85,12 +190,54 @@ __device__ __forceinline__ void adam_apply(const AdamCtx& c, int p, float g) {
     if (c.tap) c.tap[p] = g;
 }
 
+// W[k0..+3][n0..+3] gradient + Adam: per batch row one 16-byte read of X (wave-uniform) and of dY (coalesced)
+__device__ inline void blk_grad_adam_tile4(const float* X, int ldx, int K, const float* dY, int lddy, int N, int B,
+                                           const AdamCtx& c, int oW) {
+    const int kb = K >> 2, nb = N >> 2;
+    for (int it = threadIdx.x; it < kb * nb; it += kThreads) {
+        const int n0 = (it % nb) << 2;
+        const int k0 = (it / nb) << 2;
+        gf4 g[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) g[i] = gf4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; b++) {
+            const gf4 x = *reinterpret_cast<const gf4*>(&X[(size_t)b * ldx + k0]);
+            const gf4 d = *reinterpret_cast<const gf4*>(&dY[(size_t)b * lddy + n0]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) g[i] += x[i] * d;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int p = oW + (k0 + i) * N + n0;
+            gf4 th = *reinterpret_cast<const gf4*>(&c.theta[p]);
+            gf4 m = *reinterpret_cast<const gf4*>(&c.m[p]);
+            gf4 v = *reinterpret_cast<const gf4*>(&c.v[p]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float mm = m[q], vv = v[q];
+                th[q] = adam_step(th[q], g[i][q], mm, vv, c.alpha);
+                m[q] = mm; v[q] = vv;
+            }
+            *reinterpret_cast<gf4*>(&c.m[p]) = m;
+            *reinterpret_cast<gf4*>(&c.v[p]) = v;
+            *reinterpret_cast<gf4*>(&c.theta[p]) = th;
+            if (c.tap) *reinterpret_cast<gf4*>(&c.tap[p]) = g[i];
+        }
+    }
+}
+
 // gradient of a dense layer's weights/bias + Adam, one parameter element per thread-item:
 //   W[k,n] (k < K): sum_b X[b,k] dY[b,n];  W[K+j,n]: sum_b E[b,j] dY[b,n];  bias[n]: sum_b dY[b,n]
 __device__ inline void blk_dense_grad_adam(const float* X, int ldx, int K, const float* E, int Ke, const float* dY,
                                     int N, int B, const AdamCtx& c, int oW, int ob) {
     const int rows = K + Ke + 1;   // last "row" is the bias
-    for (int it = threadIdx.x; it < rows * N; it += kThreads) {
+    int first = 0;
+    if ((N & 3) == 0 && (K & 3) == 0 && (ldx & 3) == 0 && (oW & 3) == 0 && al16(X) && al16(dY) && al16(c.theta) &&
+        al16(c.m) && al16(c.v) && (c.tap == nullptr || al16(c.tap))) {
+        blk_grad_adam_tile4(X, ldx, K, dY, N, N, B, c, oW);
+        first = K * N;             // the action rows and the bias row stay on the element-wise path
+    }
+    for (int it = first + threadIdx.x; it < rows * N; it += kThreads) {
         const int n = it % N;
         const int k = it / N;
         float g = 0.0f;
@@ -111,6 +258,10 @@ __device__ inline void blk_dense_grad_adam(const float* X, int ldx, int K, const
 // dX[b,k] (+)= sum_n dY[b,n] W[k,n], optionally masked by (Hk[b,k] > 0); accumulate = add into dX
 __device__ inline void blk_dense_bwd_input_ex(const float* dY, int N, const float* W, const float* Hk, int K, float* dX,
                                               int B, bool accumulate) {
+    if ((N & 3) == 0 && (K & 3) == 0 && al16(dY) && al16(W)) {
+        blk_bwd_input_tile4(dY, N, N, W, Hk, K, dX, B, accumulate);
+        return;
+    }
     const int rb = (B + kRows - 1) / kRows;
     for (int it = threadIdx.x; it < rb * K; it += kThreads) {
         const int k = it % K;
@@ -139,6 +290,10 @@ __device__ inline void blk_dense_bwd_input_ex(const float* dY, int N, const floa
 // ---- variants with an explicit leading dimension of dY (heads that write into a strided slot array) ----
 __device__ inline void blk_dense_bwd_input_ld(const float* dY, int lddy, int N, const float* W, const float* Hk, int K,
                                               float* dX, int B, bool accumulate) {
+    if ((N & 3) == 0 && (K & 3) == 0 && (lddy & 3) == 0 && al16(dY) && al16(W)) {
+        blk_bwd_input_tile4(dY, lddy, N, W, Hk, K, dX, B, accumulate);
+        return;
+    }
     const int rb = (B + kRows - 1) / kRows;
     for (int it = threadIdx.x; it < rb * K; it += kThreads) {
         const int k = it % K;
@@ -167,7 +322,13 @@ __device__ inline void blk_dense_bwd_input_ld(const float* dY, int lddy, int N, 
 __device__ inline void blk_dense_grad_adam_ld(const float* X, int ldx, int K, const float* dY, int lddy, int N, int B,
                                               const AdamCtx& c, int oW, int ob) {
     const int rows = K + 1;   // last "row" is the bias
-    for (int it = threadIdx.x; it < rows * N; it += kThreads) {
+    int first = 0;
+    if ((N & 3) == 0 && (K & 3) == 0 && (ldx & 3) == 0 && (lddy & 3) == 0 && (oW & 3) == 0 && al16(X) && al16(dY) &&
+        al16(c.theta) && al16(c.m) && al16(c.v) && (c.tap == nullptr || al16(c.tap))) {
+        blk_grad_adam_tile4(X, ldx, K, dY, lddy, N, B, c, oW);
+        first = K * N;
+    }
+    for (int it = first + threadIdx.x; it < rows * N; it += kThreads) {
         const int n = it % N;
         const int k = it / N;
         float g = 0.0f;
