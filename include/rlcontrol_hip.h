@@ -246,6 +246,11 @@ int rlc_ddpg_rollout_create(rlc_ddpg* h, const rlc_rollout_config* cfg);
 /* advance every agent by up to n_steps training steps (stops at total_steps_limit); returns when the GPU is done.
  * out_total_steps (may be NULL) receives the training steps taken so far. */
 int rlc_ddpg_rollout_run(rlc_ddpg* h, int64_t n_steps, int64_t* out_total_steps);
+/* the same loop for a SoftActorCritic population (agents/SoftActorCritic.py:55-126): training actions are
+ * reparameterised samples of the current policy (exploration_policy 'none'), evaluation uses the mean action
+ * (sample_for_eval "False"); the N(0,1) draws come from the agent's Philox stream */
+int rlc_sac_rollout_create(rlc_sac* h, const rlc_rollout_config* cfg);
+int rlc_sac_rollout_run(rlc_sac* h, int64_t n_steps, int64_t* out_total_steps);
 /* counts of one agent: finished training episodes, evaluations run, training steps taken */
 int rlc_rollout_counts(rlc_handle* h, int32_t agent, int64_t* n_train_episodes, int64_t* n_evals,
                        int64_t* total_steps);

@@ -12,8 +12,8 @@ offline tooling reads identical fields).  Differences: no TensorFlow summary wri
 and ``--gpu`` picks the HIP device.
 
 ``--device_rollout`` runs ALL indices of the range concurrently as one population on the GPU with the
-environment simulated on the device (rlcontrol_amd/device_experiment.py; DDPG on Pendulum-v0): same
-schedule, same pickle, Philox random streams instead of numpy's.
+environment simulated on the device (rlcontrol_amd/device_experiment.py; DDPG or SoftActorCritic on Pendulum-v0):
+same schedule, same pickle, Philox random streams instead of numpy's.
 
 Under ``python -m torch.distributed.run --nproc-per-node N main.py ...`` the INDEX range is dealt round-robin to
 the N ranks (one GPU each, nothing exchanged while training); one all-gather of the run records at the end
@@ -81,17 +81,59 @@ def _run_data(random_seed, env_json, result):
 
 
 # Config attributes that must be equal across the agents of one device population (everything except the
-# per-agent learning rates and the seed)
-_SHARED_KEYS = ("shared_l1_dim", "actor_l2_dim", "critic_l2_dim", "batch_size", "buffer_size", "tau", "gamma",
-                "warmup_steps", "norm_type", "exploration_policy", "ou_theta", "ou_mu", "ou_sigma")
+# per-agent learning rates / entropy scale and the seed)
+_SHARED_KEYS = {
+    "DDPG": ("shared_l1_dim", "actor_l2_dim", "critic_l2_dim", "batch_size", "buffer_size", "tau", "gamma",
+             "warmup_steps", "norm_type", "exploration_policy", "ou_theta", "ou_mu", "ou_sigma"),
+    "SoftActorCritic": ("actor_l1_dim", "actor_l2_dim", "critic_l1_dim", "critic_l2_dim", "batch_size", "buffer_size",
+                        "tau", "gamma", "warmup_steps", "norm_type", "exploration_policy", "sample_for_eval"),
+}
+
+
+def _make_population(agent_name, members, arg_params):
+    """One population handle for a group of (index, sweep, agent_params, config) that share the network shape."""
+    c0 = members[0][3]
+    seeds = [np.uint64(m[3].random_seed) for m in members]
+    device = int(arg_params.get("device", 0))
+    if agent_name == "DDPG":
+        from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
+        if c0.exploration_policy != 'ou_noise':
+            raise RuntimeError("the device loop implements DDPG's 'ou_noise' exploration policy only")
+        pop = DDPGPopulation(
+            n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, shared_l1_dim=c0.shared_l1_dim,
+            actor_l2_dim=c0.actor_l2_dim, critic_l2_dim=c0.critic_l2_dim, batch_size=c0.batch_size,
+            buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min, state_max=c0.state_max,
+            action_min=c0.action_min, action_max=c0.action_max, actor_lr=[m[3].actor_lr for m in members],
+            critic_lr=[m[3].critic_lr for m in members], seeds=seeds, clip_state=(c0.norm_type != 'none'),
+            ou_theta=c0.ou_theta, ou_mu=c0.ou_mu, ou_sigma=c0.ou_sigma, device=device)
+        for i, m in enumerate(members):
+            pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.shared_l1_dim, c0.actor_l2_dim,
+                                          c0.critic_l2_dim, m[3].random_seed), init_target=True)
+        return pop
+    from rlcontrol_amd.hip_sac import SACPopulation, init_params
+    if c0.exploration_policy != 'none' or c0.sample_for_eval == "True" or c0.norm_type == 'none':
+        raise RuntimeError("the device loop implements SoftActorCritic with exploration_policy 'none', "
+                           "sample_for_eval 'False' and an input norm (the shipped sac.json)")
+    pop = SACPopulation(
+        n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, actor_l1_dim=c0.actor_l1_dim,
+        actor_l2_dim=c0.actor_l2_dim, critic_l1_dim=c0.critic_l1_dim, critic_l2_dim=c0.critic_l2_dim,
+        batch_size=c0.batch_size, buffer_size=int(c0.buffer_size), tau=c0.tau,
+        state_min0=float(np.asarray(c0.state_min).reshape(-1)[0]), state_max0=float(np.asarray(c0.state_max).reshape(-1)[0]),
+        action_max0=float(np.asarray(c0.action_max).reshape(-1)[0]), pi_lr=[m[3].pi_lr for m in members],
+        qf_vf_lr=[m[3].qf_vf_lr for m in members], entropy_scale=[m[3].entropy_scale for m in members], seeds=seeds,
+        clip_state=True, device=device)
+    for i, m in enumerate(members):
+        pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.actor_l1_dim, c0.actor_l2_dim, c0.critic_l1_dim,
+                                      c0.critic_l2_dim, m[3].random_seed), init_target=True)
+    return pop
 
 
 def run_indices_on_device(indices, agent_json, env_json, env_params, arg_params, data, verbose=True, progress=None):
-    """All `indices` at once: one DDPG population per group of indices that share the network / replay shape."""
+    """All `indices` at once: one population per group of indices that share the network / replay shape."""
     from rlcontrol_amd.device_experiment import DeviceExperiment
-    from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
-    if agent_json['agent'] != 'DDPG':
-        raise RuntimeError("--device_rollout is built for the DDPG agent (got %r)" % agent_json['agent'])
+    agent_name = agent_json['agent']
+    if agent_name not in _SHARED_KEYS:
+        raise RuntimeError("--device_rollout is built for the DDPG and SoftActorCritic agents (got %r)" % agent_name)
     groups = OrderedDict()
     for index in indices:
         agent_params, total_num_sweeps = get_sweep_parameters(agent_json['sweeps'], index)
@@ -99,24 +141,12 @@ def run_indices_on_device(indices, agent_json, env_json, env_params, arg_params,
         config.merge_config(env_params)
         config.merge_config(agent_params)
         config.merge_config(dict(arg_params, random_seed=int(index / total_num_sweeps)))
-        if config.exploration_policy != 'ou_noise':
-            raise RuntimeError("the device loop implements the 'ou_noise' exploration policy only")
-        key = tuple(str(getattr(config, k)) for k in _SHARED_KEYS)
+        key = tuple(str(getattr(config, k, None)) for k in _SHARED_KEYS[agent_name])
         groups.setdefault(key, []).append((index, index % total_num_sweeps, dict(agent_params), config))
     out = {}
     for members in groups.values():
         c0 = members[0][3]
-        pop = DDPGPopulation(
-            n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, shared_l1_dim=c0.shared_l1_dim,
-            actor_l2_dim=c0.actor_l2_dim, critic_l2_dim=c0.critic_l2_dim, batch_size=c0.batch_size,
-            buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min, state_max=c0.state_max,
-            action_min=c0.action_min, action_max=c0.action_max, actor_lr=[m[3].actor_lr for m in members],
-            critic_lr=[m[3].critic_lr for m in members], seeds=[np.uint64(m[3].random_seed) for m in members],
-            clip_state=(c0.norm_type != 'none'), ou_theta=c0.ou_theta, ou_mu=c0.ou_mu, ou_sigma=c0.ou_sigma,
-            device=int(arg_params.get("device", 0)))
-        for i, m in enumerate(members):
-            pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.shared_l1_dim, c0.actor_l2_dim,
-                                          c0.critic_l2_dim, m[3].random_seed), init_target=True)
+        pop = _make_population(agent_name, members, arg_params)
         exp = DeviceExperiment(pop, env_json, gamma=c0.gamma, warmup_steps=c0.warmup_steps)
         if verbose:
             print("device rollout: %d agents, %d steps each" % (len(members), exp.total_steps_limit))

@@ -18,6 +18,8 @@ import numpy as np
 from . import philox
 from .ddpg import DDPGOracle
 
+KEY_SAC_EPS = 0x9E3779B97F4A7C15     # sac_policy.h: the agent's N(0,1) stream (acting and minibatch draws)
+
 
 class Pendulum(object):
     def __init__(self, key):
@@ -58,7 +60,7 @@ class RolloutOracle(object):
     def __init__(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_min, action_max, seed,
                  batch_size, buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval,
                  eval_episodes, ou_theta=0.15, ou_mu=0.0, ou_sigma=0.2, clip_state=True):
-        self.net = DDPGOracle(dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state)
+        self.net = self._make_net(dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state)
         self.seed = int(seed)
         self.B, self.cap = int(batch_size), int(buffer_size)
         self.gamma, self.warmup = float(gamma), int(warmup_steps)
@@ -68,7 +70,7 @@ class RolloutOracle(object):
         self.amax = np.asarray(action_max, np.float32).reshape(-1)
         f = np.float32
         self.ou_theta, self.ou_mu, self.ou_sigma = f(ou_theta), f(ou_mu), f(ou_sigma)
-        self.A = dims.A
+        self.A = dims.A if hasattr(dims, "A") else dims.tuple()[1]
         self.noise = np.full(self.A, self.ou_mu, np.float32)
         self.noise_ctr = 0
         self.sample_ctr = 0
@@ -80,6 +82,14 @@ class RolloutOracle(object):
         self.train_ret, self.train_len, self.train_cum = [], [], []
         self.eval_ret, self.eval_len, self.timesteps_at_eval = [], [], []
         self.n_updates = 0
+
+    def _make_net(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state):
+        return DDPGOracle(dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state)
+
+    def _learn(self, rows):
+        self.net.update(np.array([r[0] for r in rows]), np.array([r[1] for r in rows]),
+                        np.array([r[3] for r in rows]), np.array([r[2] for r in rows]),
+                        np.array([r[4] for r in rows]))
 
     # -- agent ---------------------------------------------------------------------------------
     def agent_reset(self):
@@ -111,9 +121,7 @@ class RolloutOracle(object):
             idx = philox.sample_distinct(len(self.replay), self.B, self.seed, self.sample_ctr)
             self.sample_ctr += 1
             rows = [self.replay[i] for i in idx]
-            self.net.update(np.array([r[0] for r in rows]), np.array([r[1] for r in rows]),
-                            np.array([r[3] for r in rows]), np.array([r[2] for r in rows]),
-                            np.array([r[4] for r in rows]))
+            self._learn(rows)
             self.n_updates += 1
 
     # -- experiment ------------------------------------------------------------------------------
@@ -166,3 +174,42 @@ class RolloutOracle(object):
                 self.train_cum.append(self.total)
         self.last_obs, self.last_step = obs, step
         return self
+
+
+class SacRolloutOracle(RolloutOracle):
+    """One SoftActorCritic agent of the on-device loop (sac_rollout_device.h): training actions are reparameterised
+    samples of the current policy, evaluation uses the mean action, no exploration-noise state."""
+
+    def __init__(self, dims, theta, pi_lr, qv_lr, alpha, tau, smin0, smax0, amax0, seed, batch_size, buffer_size, gamma,
+                 warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes):
+        self._sac = (pi_lr, qv_lr, alpha, smin0, smax0, amax0)
+        RolloutOracle.__init__(self, dims, theta, 0.0, 0.0, tau, None, None, [-amax0], [amax0], seed, batch_size,
+                               buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes)
+
+    def _make_net(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state):
+        from .sac import SACOracle
+        pi_lr, qv_lr, alpha, smin0, smax0, amax0 = self._sac
+        return SACOracle(dims, theta, pi_lr, qv_lr, alpha, tau, smin0, smax0, amax0)
+
+    def agent_reset(self):
+        pass
+
+    def _normal(self, ctr_hi_base, k):
+        p = philox.philox4x32_10(self.seed ^ KEY_SAC_EPS, self.noise_ctr, ctr_hi_base + (k >> 1))
+        return philox.normal2(p)[k & 1]
+
+    def act(self, obs, is_train):
+        x = np.asarray(obs, np.float64).astype(np.float32).reshape(1, -1)
+        if not is_train:
+            return self.net.act(x)[0]
+        eps = np.array([[self._normal(0x4000000000000000, j) for j in range(self.A)]], np.float32)
+        self.noise_ctr += 1
+        return self.net.act(x, eps=eps)[0]
+
+    def _learn(self, rows):
+        B = len(rows)
+        eps = np.array([[self._normal(0, b * self.A + j) for j in range(self.A)] for b in range(B)], np.float32)
+        self.noise_ctr += 1
+        self.net.update(np.array([r[0] for r in rows]), np.array([r[1] for r in rows]),
+                        np.array([r[3] for r in rows]), np.array([r[2] for r in rows]),
+                        np.array([r[4] for r in rows]), eps)

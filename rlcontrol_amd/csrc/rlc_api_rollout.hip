@@ -2,6 +2,7 @@
 // Host side = the schedule of experiment.py:52-161 (evaluation 0, then train step / update / periodic
 // evaluation); all per-agent state lives on the GPU (rollout_kernels.hip).
 #include "rlc_handle.h"
+#include "sac_rollout_device.h"
 
 #define RLC_NEED_DDPG(h) RLC_REQUIRE((h) && (h)->algo == RLC_ALGO_DDPG, "handle is not a DDPG population")
 #define RLC_NEED_ENV(h) RLC_REQUIRE((h) && (h)->has_env, "no rollout configured on this handle (rlc_ddpg_rollout_create)")
@@ -19,26 +20,25 @@ static int launch_steps(rlc_handle* h, int n, int q8_first) {
 
 extern "C" {
 
-int rlc_ddpg_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
-    RLC_REQUIRE(h && cfg, "null argument");
-    RLC_NEED_DDPG(h);
+// environment state, bookkeeping and logs of a population (any algorithm)
+static int rollout_alloc(rlc_handle* h, const rlc_rollout_config* cfg) {
     RLC_REQUIRE(!h->has_env, "rollout already configured on this handle");
     if (rlc_h_use_device(h)) return 1;
     RLC_REQUIRE(cfg->env_id == RLC_ENV_PENDULUM_V0, "unknown env_id %d (built in: RLC_ENV_PENDULUM_V0)", cfg->env_id);
-    RLC_REQUIRE(h->dv.d.S == 3 && h->dv.d.A == 1, "Pendulum-v0 needs state_dim 3 / action_dim 1 (handle has %d / %d)",
-                h->dv.d.S, h->dv.d.A);
+    RLC_REQUIRE(h->rep.S == 3 && h->rep.A == 1, "Pendulum-v0 needs state_dim 3 / action_dim 1 (handle has %d / %d)",
+                h->rep.S, h->rep.A);
     RLC_REQUIRE(cfg->episode_steps_limit >= 1 && cfg->total_steps_limit >= 0 && cfg->eval_interval >= 1 &&
                 cfg->eval_episodes >= 0 && cfg->warmup_steps >= 0 && cfg->max_train_episodes >= 1,
                 "bad rollout configuration");
     RlcEnvDev& e = h->env;
     e.env_id = RLC_ENV_PENDULUM;
     e.episode_limit = cfg->episode_steps_limit;
-    e.learn_threshold = cfg->warmup_steps > h->dv.d.B ? cfg->warmup_steps : h->dv.d.B;
+    e.learn_threshold = cfg->warmup_steps > h->B ? cfg->warmup_steps : h->B;
     e.eval_episodes = cfg->eval_episodes;
     e.max_episodes = cfg->max_train_episodes;
     e.max_evals = (int)(cfg->total_steps_limit / cfg->eval_interval) + 1;
     e.gamma = cfg->gamma;
-    const size_t NA = h->dv.n_agents, S = h->dv.d.S;
+    const size_t NA = h->rep.n_agents, S = h->rep.S;
     const size_t nev = NA * (size_t)e.max_evals * (e.eval_episodes ? e.eval_episodes : 1);
     if (rlc_h_malloc(h, &e.sim, NA * RLC_ENV_STATE) || rlc_h_malloc(h, &e.obs, NA * S) ||
         rlc_h_malloc(h, &e.ep_step, NA) || rlc_h_malloc(h, &e.ep_ret, NA) || rlc_h_malloc(h, &e.need_reset, NA) ||
@@ -49,43 +49,75 @@ int rlc_ddpg_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
         return 1;
     std::vector<int> ones(NA, 1);
     RLC_HIP(hipMemcpyAsync(e.need_reset, ones.data(), NA * sizeof(int), hipMemcpyHostToDevice, h->st));
-    // device-resident argument block of the fused launches
-    if (rlc_h_malloc(h, &h->rollout_dev, 1)) return 1;
-    RlcRollout ro;
-    ro.dv = h->dv;
-    ro.env = e;
-    RLC_HIP(hipMemcpyAsync(h->rollout_dev, &ro, sizeof(ro), hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     h->ro_total_limit = cfg->total_steps_limit;
     h->ro_eval_interval = cfg->eval_interval;
     h->ro_steps = 0;
     h->ro_evals = 0;
     h->ro_pending_q8 = 0;
+    return 0;
+}
+
+int rlc_ddpg_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
+    RLC_REQUIRE(h && cfg, "null argument");
+    RLC_NEED_DDPG(h);
+    if (rollout_alloc(h, cfg)) return 1;
+    // device-resident argument block of the fused launches
+    if (rlc_h_malloc(h, &h->rollout_dev, 1)) return 1;
+    RlcRollout ro;
+    ro.dv = h->dv;
+    ro.env = h->env;
+    RLC_HIP(hipMemcpyAsync(h->rollout_dev, &ro, sizeof(ro), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
     h->has_env = true;
     return 0;
 }
 
-int rlc_ddpg_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
-    RLC_NEED_ENV(h);
-    RLC_NEED_DDPG(h);
+int rlc_sac_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
+    RLC_REQUIRE(h && cfg, "null argument");
+    RLC_REQUIRE(h->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population");
+    if (rollout_alloc(h, cfg)) return 1;
+    if (rlc_h_malloc(h, &h->sac_rollout_dev, 1)) return 1;
+    RlcSacRollout ro;
+    ro.dv = h->sac;
+    ro.env = h->env;
+    RLC_HIP(hipMemcpyAsync(h->sac_rollout_dev, &ro, sizeof(ro), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    h->has_env = true;
+    return 0;
+}
+
+// the schedule of experiment.py:52-161 for either algorithm
+static int rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
     if (rlc_h_use_device(h)) return 1;
     RLC_REQUIRE(n_steps >= 0, "negative n_steps");
+    const bool sac = h->algo == RLC_ALGO_SAC;
     auto eval_now = [&]() -> int {
-        if (h->env.eval_episodes > 0 && rlc_launch_ddpg_eval(h->dv, h->env, (int)h->ro_evals, h->st)) return 1;
+        if (h->env.eval_episodes > 0) {
+            if (sac ? rlc_launch_sac_eval(h->sac, h->env, (int)h->ro_evals, h->st)
+                    : rlc_launch_ddpg_eval(h->dv, h->env, (int)h->ro_evals, h->st))
+                return 1;
+        }
         h->ro_evals += 1;
         return 0;
     };
     if (h->ro_steps == 0 && h->ro_evals == 0)          // experiment.py:57-58: evaluate before any training
         if (eval_now()) return 1;
     // one launch per stretch between evaluations (experiment.py:131-133); kMaxPerLaunch bounds a launch's run time
-    const long long kMaxPerLaunch = 2000;
+    const long long kMaxPerLaunch = sac ? 500 : 2000;
     long long todo = n_steps;
     if (todo > h->ro_total_limit - h->ro_steps) todo = h->ro_total_limit - h->ro_steps;
     while (todo > 0) {
         long long n = h->ro_eval_interval - h->ro_steps % h->ro_eval_interval;      // steps to the next evaluation
         if (n > todo) n = todo;
         if (n > kMaxPerLaunch) n = kMaxPerLaunch;
-        if (launch_steps(h, (int)n, h->ro_pending_q8)) return 1;
+        if (sac) {
+            if (rlc_launch_sac_update(h->sac, 0, h->sac.n_agents, (int)n, RLC_SRC_REPLAY_DEVICE_SAMPLER, nullptr, nullptr, 0,
+                                      h->st, h->sac_rollout_dev))
+                return 1;
+        } else if (launch_steps(h, (int)n, h->ro_pending_q8)) {
+            return 1;
+        }
         h->ro_pending_q8 = 0;
         h->ro_steps += n;
         todo -= n;
@@ -100,6 +132,18 @@ int rlc_ddpg_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_step
     RLC_HIP(hipStreamSynchronize(h->st));
     if (out_total_steps) *out_total_steps = h->ro_steps;
     return 0;
+}
+
+int rlc_ddpg_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
+    RLC_NEED_ENV(h);
+    RLC_NEED_DDPG(h);
+    return rollout_run(h, n_steps, out_total_steps);
+}
+
+int rlc_sac_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
+    RLC_NEED_ENV(h);
+    RLC_REQUIRE(h->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population");
+    return rollout_run(h, n_steps, out_total_steps);
 }
 
 int rlc_rollout_counts(rlc_handle* h, int32_t agent, int64_t* n_train_episodes, int64_t* n_evals,
@@ -150,7 +194,7 @@ int rlc_rollout_observation(rlc_handle* h, int32_t agent, double* obs, int32_t* 
     if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
     RLC_NEED_ENV(h);
     RLC_REQUIRE(obs && episode_step, "null output");
-    const size_t S = h->dv.d.S;
+    const size_t S = h->rep.S;
     RLC_HIP(hipMemcpyAsync(obs, h->env.obs + (size_t)agent * S, sizeof(double) * S, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipMemcpyAsync(episode_step, h->env.ep_step + agent, sizeof(int), hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));

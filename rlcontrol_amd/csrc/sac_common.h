@@ -54,8 +54,12 @@ struct RlcSacDev {
 
 size_t rlc_sac_scratch_floats(const RlcSacDims& d);
 // eps_dev: [n_agents][n_updates][B][A] injected N(0,1) draws, or null -> device Philox
+struct RlcSacRollout;   // sac_rollout_device.h: {RlcSacDev, RlcEnvDev} in device memory
+// rollout (device pointer, may be null): every iteration first takes one environment step of the on-device loop
 int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st);
+                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
+                          const RlcSacRollout* rollout = nullptr);
+int rlc_launch_sac_eval(const RlcSacDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);
 // one state per agent; sample = 0 mean action, 1 reparameterised sample (eps_dev [n][A] or null -> Philox)
 int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
                        int sample, float* out_dev, hipStream_t st);

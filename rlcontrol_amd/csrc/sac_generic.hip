@@ -13,6 +13,7 @@
 // r and gamma enter fp32 placeholders in this agent (sac_network.py:51-52), so the replay's float64
 // values are cast to fp32 at gather time.
 #include "generic_blocks.h"
+#include "sac_rollout_device.h"
 #include "sac_common.h"
 
 namespace {
@@ -25,6 +26,7 @@ struct SLds {
     long long* idx;
     int* pool;
     int* dups;
+    float* pol;       // scratch of the on-device training step (sac_rollout_device.h)
 };
 
 __host__ __device__ inline size_t slds_carve(const RlcSacDims& d, unsigned char* base, SLds* out) {
@@ -47,12 +49,9 @@ __host__ __device__ inline size_t slds_carve(const RlcSacDims& d, unsigned char*
     L.red = (float*)take(sizeof(float) * 16);
     L.pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     L.dups = (int*)take(sizeof(int) * 4);
+    L.pol = (float*)take(sizeof(float) * (sac_policy_lds_floats(d) + 4));
     if (out) *out = L;
     return off;
-}
-
-__device__ __forceinline__ float clip_scalar(float v, int on, float lo, float hi) {
-    return on ? fminf(fmaxf(v, lo), hi) : v;
 }
 
 // block-wide sum of v over threads (fixed order: deterministic); result broadcast to all threads
@@ -69,7 +68,8 @@ __device__ inline float blk_sum(float v, float* red) {
 
 __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, int first_agent, int n_updates,
                                                                   int source, const long long* host_idx,
-                                                                  const float* eps_in, int grad_taps) {
+                                                                  const float* eps_in, int grad_taps,
+                                                                  const RlcSacRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcSacDims d = dv.d;
     const int S = d.S, A = d.A, L1A = d.L1A, L2A = d.L2A, L1C = d.L1C, L2C = d.L2C, B = d.B;
@@ -104,6 +104,10 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
     const float EPS = 1e-6f, LOG2PI = 1.8378770664093453f, HALF_RANGE = 0.5f * (2.0f - (-20.0f));
 
     for (int u = 0; u < n_updates; u++) {
+        if (rollout) {
+            // on-device experiment loop: one environment step first; update when learn() would run
+            if (!rlc_sac_train_step_device(rollout, agent, L.pol)) continue;
+        }
         // ---- sample + gather ----
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
@@ -129,8 +133,8 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
             }
             for (int i = 0; i < S; i++) {
                 L.x[b * S + i] = ps[i];
-                L.xc[b * S + i] = clip_scalar(ps[i], dv.clip_state, dv.smin0, dv.smax0);
-                L.x2c[b * S + i] = clip_scalar(ps2[i], dv.clip_state, dv.smin0, dv.smax0);
+                L.xc[b * S + i] = rlc_clip_scalar(ps[i], dv.clip_state, dv.smin0, dv.smax0);
+                L.x2c[b * S + i] = rlc_clip_scalar(ps2[i], dv.clip_state, dv.smin0, dv.smax0);
             }
             for (int j = 0; j < A; j++) {
                 L.a[b * A + j] = pa[j];
@@ -284,57 +288,57 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_act_kernel(RlcSacDev dv, int
                                                                const float* eps_in, int sample, float* out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcSacDims d = dv.d;
-    const int S = d.S, A = d.A, L1A = d.L1A, L2A = d.L2A;
+    const int S = d.S, A = d.A;
     const int agent = first_agent + blockIdx.x, tid = threadIdx.x;
-    float* x = (float*)smem;
-    float* h1 = x + ((S + 3) & ~3);
-    float* h2 = h1 + ((L1A + 3) & ~3);
+    const SacPolicyLds L = sac_policy_carve(d, (float*)smem);
     const float* th = dv.theta + (size_t)agent * d.Ppad;
     for (int i = tid; i < S; i += kThreads)
-        x[i] = clip_scalar(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin0, dv.smax0);
-    __syncthreads();
-    for (int k = tid; k < L1A; k += kThreads) {
-        float acc = 0.0f;
-        for (int i = 0; i < S; i++) acc += x[i] * th[d.pW1 + i * L1A + k];
-        h1[k] = fmaxf(acc + th[d.pb1 + k], 0.0f);
+        L.x[i] = rlc_clip_scalar(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin0, dv.smax0);
+    if (sample && tid < A)
+        L.eps[tid] = eps_in ? eps_in[(size_t)blockIdx.x * A + tid] : sac_act_eps(dv.rep.seed[agent], dv.noise_ctr[agent], tid);
+    sac_policy_forward(d, th, L, dv.amax0, sample);
+    if (tid < A) out[(size_t)blockIdx.x * A + tid] = L.out[tid];
+    if (sample && !eps_in && tid == 0) dv.noise_ctr[agent] += 1;
+}
+
+// evaluation of the on-device loop: one greedy (mean-action) test episode per workgroup
+// (run_episode_eval, experiment.py:163-196; agents/SoftActorCritic.py:102)
+__global__ __launch_bounds__(kThreads) void rlc_sac_eval_kernel(RlcSacDev dv, RlcEnvDev env, int eval_round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double sim[RLC_ENV_STATE];
+    __shared__ double obs[8];
+    __shared__ int s_done;
+    const RlcSacDims d = dv.d;
+    const int S = d.S;
+    const int agent = blockIdx.x / env.eval_episodes, ep = blockIdx.x % env.eval_episodes;
+    const int tid = threadIdx.x;
+    const SacPolicyLds L = sac_policy_carve(d, (float*)smem);
+    const float* th = dv.theta + (size_t)agent * d.Ppad;
+    if (tid == 0) {
+        env_reset(env.env_id, sim, obs, dv.rep.seed[agent] ^ RLC_KEY_ENV_TEST,
+                  (unsigned long long)eval_round * env.eval_episodes + ep);
+        s_done = 0;
     }
     __syncthreads();
-    for (int n = tid; n < L2A; n += kThreads) {
-        float acc = 0.0f;
-        for (int k = 0; k < L1A; k++) acc += h1[k] * th[d.pW2 + (size_t)k * L2A + n];
-        h2[n] = fmaxf(acc + th[d.pb2 + n], 0.0f);
-    }
-    __syncthreads();
-    const int wave = tid / 64, lane = tid % 64;
-    const unsigned long long nctr = dv.noise_ctr[agent];
-    for (int j = wave; j < A; j += kThreads / 64) {
-        float am = 0.0f, as = 0.0f;
-        for (int n = lane; n < L2A; n += 64) {
-            am += h2[n] * th[d.pWm + n * A + j];
-            as += h2[n] * th[d.pWs + n * A + j];
+    double ret = 0.0;
+    int steps = 0;
+    while (steps < env.episode_limit) {
+        for (int i = tid; i < S; i += kThreads) L.x[i] = rlc_clip_scalar((float)obs[i], dv.clip_state, dv.smin0, dv.smax0);
+        sac_policy_forward(d, th, L, dv.amax0, 0);
+        if (tid == 0) {
+            double reward;
+            s_done = env_step(env.env_id, sim, L.out, obs, &reward, steps + 1, env.episode_limit);
+            ret += reward;
         }
-        for (int off = 32; off > 0; off >>= 1) { am += __shfl_down(am, off, 64); as += __shfl_down(as, off, 64); }
-        if (lane == 0) {
-            float u = am + th[d.pbm + j];
-            if (sample) {
-                const float log_std = -20.0f + 0.5f * (2.0f - (-20.0f)) * (tanhf(as + th[d.pbs + j]) + 1.0f);
-                float e;
-                if (eps_in) {
-                    e = eps_in[(size_t)blockIdx.x * A + j];
-                } else {
-                    const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ 0x9E3779B97F4A7C15ull, nctr,
-                                                    0x4000000000000000ull + (unsigned long long)(j >> 1));
-                    float n0, n1;
-                    philox_normal2(p, n0, n1);
-                    e = (j & 1) ? n1 : n0;
-                }
-                u += e * expf(log_std);
-            }
-            out[(size_t)blockIdx.x * A + j] = tanhf(u) * dv.amax0;
-        }
+        steps++;
+        __syncthreads();
+        if (s_done) break;
     }
-    __syncthreads();
-    if (sample && !eps_in && tid == 0) dv.noise_ctr[agent] = nctr + 1;
+    if (tid == 0 && eval_round < env.max_evals) {
+        const size_t at = ((size_t)agent * env.max_evals + eval_round) * env.eval_episodes + ep;
+        env.eval_ret[at] = ret;
+        env.eval_len[at] = steps;
+    }
 }
 
 }  // namespace
@@ -345,8 +349,10 @@ size_t rlc_sac_scratch_floats(const RlcSacDims& d) {
 }
 
 int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st) {
+                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
+                          const RlcSacRollout* rollout) {
     const size_t lds = slds_carve(dv.d, nullptr, nullptr);
+    RLC_REQUIRE(!(rollout && eps_dev), "the on-device loop draws its own eps");
     RLC_REQUIRE(lds <= 160 * 1024, "SAC kernel needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr = false;
     if (!attr) {
@@ -355,16 +361,24 @@ int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, in
         attr = true;
     }
     hipLaunchKernelGGL(rlc_sac_update_kernel, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates,
-                       source, idx_dev, eps_dev, grad_taps);
+                       source, idx_dev, eps_dev, grad_taps, rollout);
     RLC_HIP(hipGetLastError());
     return 0;
 }
 
 int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
                        int sample, float* out_dev, hipStream_t st) {
-    const size_t lds = sizeof(float) * (((dv.d.S + 3) & ~3) + ((dv.d.L1A + 3) & ~3) + ((dv.d.L2A + 3) & ~3));
+    const size_t lds = sizeof(float) * sac_policy_lds_floats(dv.d);
     hipLaunchKernelGGL(rlc_sac_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, eps_dev,
                        sample, out_dev);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
+int rlc_launch_sac_eval(const RlcSacDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st) {
+    const size_t lds = sizeof(float) * sac_policy_lds_floats(dv.d);
+    hipLaunchKernelGGL(rlc_sac_eval_kernel, dim3(dv.n_agents * env.eval_episodes), dim3(kThreads), lds, st, dv, env,
+                       eval_round);
     RLC_HIP(hipGetLastError());
     return 0;
 }

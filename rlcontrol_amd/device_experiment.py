@@ -1,9 +1,9 @@
 """Experiment.run() of the reference (experiment.py:52-217) for a whole population, environment on the GPU.
 
 ``DeviceExperiment(population, env_params, gamma, warmup_steps)`` drives the C ABI's rollout block
-(include/rlcontrol_hip.h): every agent of a ``DDPGPopulation`` runs its own train / evaluate loop on the
-device -- act (+OU), Pendulum step, replay insert, gated fused update, periodic greedy evaluation -- with
-no host round trip per step.  ``run()`` returns, per agent, the reference's 9-tuple
+(include/rlcontrol_hip.h): every agent of a ``DDPGPopulation`` (act + OU noise) or ``SACPopulation``
+(reparameterised sample of the policy) runs its own train / evaluate loop on the device -- act, Pendulum step,
+replay insert, gated fused update, periodic greedy evaluation -- with no host round trip per step.  ``run()`` returns, per agent, the reference's 9-tuple
 (train_rewards_per_episode, eval_rewards_per_episode, train_steps_per_episode, eval_steps_per_episode,
 timesteps_at_eval, cum_train_time, cum_eval_time, train_episodes, train_cum_steps).
 
@@ -45,7 +45,8 @@ class DeviceExperiment(object):
         cfg.max_train_episodes = int(max_train_episodes)
         cfg.gamma = float(gamma)
         self._max_ep = int(max_train_episodes)
-        check(population._lib.rlc_ddpg_rollout_create(population._h, ctypes.byref(cfg)))
+        self._prefix = "rlc_sac" if type(population).__name__ == "SACPopulation" else "rlc_ddpg"
+        check(getattr(population._lib, self._prefix + "_rollout_create")(population._h, ctypes.byref(cfg)))
         self.total_steps = 0
         self.wall = 0.0
 
@@ -53,7 +54,8 @@ class DeviceExperiment(object):
         """up to n_steps more training steps for every agent; returns the steps taken so far"""
         out = ctypes.c_int64(0)
         t0 = time.time()
-        check(self.pop._lib.rlc_ddpg_rollout_run(self.pop._h, ctypes.c_int64(int(n_steps)), ctypes.byref(out)))
+        check(getattr(self.pop._lib, self._prefix + "_rollout_run")(self.pop._h, ctypes.c_int64(int(n_steps)),
+                                                                    ctypes.byref(out)))
         self.wall += time.time() - t0
         self.total_steps = int(out.value)
         return self.total_steps

@@ -202,3 +202,76 @@ def test_rollout_ring_eviction_matches_fifo(hip_lib):
     assert np.array_equal(same, osame)
     with pytest.raises(Exception):
         pop.replay_gather(0, [cap])          # index out of range (custom_collections.py:48,58)
+
+
+def test_sac_rollout_matches_cpu_restatement(hip_lib):
+    """The on-device loop for a SoftActorCritic population (sac_rollout_device.h) against oracle/rollout.py's
+    SacRolloutOracle on the same Philox streams: exact bookkeeping, trajectory within the drift the closed loop
+    amplifies (see the module docstring)."""
+    from oracle.rollout import SacRolloutOracle
+    from oracle.sac import SacDims, init_params
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    from rlcontrol_amd.hip_sac import SACPopulation
+    dims, B = (3, 1, 32, 32, 32, 32), 16
+    seeds, pi_lr, qv_lr, alpha = [21, 99999999999], [1e-3, 5e-4], [1e-3, 2e-3], [0.2, 0.05]
+    pop = SACPopulation(2, *dims, B, 4096, 0.01, -8.0, 8.0, 2.0, pi_lr, qv_lr, alpha, seeds=seeds)
+    d = SacDims(*dims)
+    thetas = []
+    for i in range(2):
+        th = init_params(d, 300 + i)
+        lay, _ = d.layout()
+        off, shp = lay["pWs"]
+        th[off:off + int(np.prod(shp))] *= 0.02          # well-conditioned log-std head (tests/test_sac.py)
+        thetas.append(th)
+        pop.set_params(i, th, init_target=True)
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00009, "EpisodeSteps": 25,
+           "EvalIntervalMilSteps": 0.00004, "EvalEpisodes": 2}
+    exp = DeviceExperiment(pop, env, gamma=0.99, warmup_steps=0)
+    assert exp.advance(37) == 37
+    exp.advance(1000)
+    assert exp.total_steps == 90
+    res = exp.results()
+    for a in range(2):
+        orc = SacRolloutOracle(d, thetas[a], pi_lr[a], qv_lr[a], alpha[a], 0.01, -8.0, 8.0, 2.0, seeds[a], B, 4096, 0.99,
+                               0, 25, 90, 40, 2).run()
+        tr, er, tl, el, ts, _, _, n_started, tc = res[a]
+        assert tl == orc.train_len == [25] * 3 and tc == orc.train_cum == [25, 50, 75]
+        assert ts == orc.timesteps_at_eval == [0, 40, 80] and el == orc.eval_len and n_started == 4
+        assert pop.replay_size(a) == len(orc.replay) == 90 - 3
+        s, act, r, s2, g = pop.replay_gather(a, np.arange(87))
+        os_ = np.array([t[0] for t in orc.replay]); oa = np.array([t[1] for t in orc.replay])
+        pre = B + 1
+        assert np.allclose(s[:pre], os_[:pre], atol=2e-6) and np.allclose(act[:pre], oa[:pre], atol=5e-6)
+        assert np.allclose(s, os_, atol=5e-3) and np.allclose(act, oa, atol=5e-3)
+        assert np.allclose(er[0], orc.eval_ret[0], rtol=1e-5, atol=1e-4)      # evaluation 0: initial weights, mean action
+        assert np.allclose(er, orc.eval_ret, rtol=5e-3, atol=5e-2)
+        th = pop.get_blob(a, "theta")
+        assert np.max(np.abs(th - orc.net.theta)) < 5e-3 * np.max(np.abs(orc.net.theta))
+        assert np.allclose(pop.get_beta_powers(a), orc.net.pw, rtol=1e-6)
+    pop.close()
+
+
+def test_main_device_rollout_sac_pickle(hip_lib, tmp_path):
+    """main.py --device_rollout with the SoftActorCritic agent: per-agent pi_lr / entropy_scale from the sweep."""
+    import json
+    import pickle
+    import main as drv
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00012, "EpisodeSteps": 50,
+           "EvalIntervalMilSteps": 0.00005, "EvalEpisodes": 2}
+    agent = {"agent": "SoftActorCritic",
+             "sweeps": {"norm_type": ["input_norm"], "exploration_policy": ["none"], "actor_l1_dim": [32],
+                        "actor_l2_dim": [32], "critic_l1_dim": [32], "critic_l2_dim": [32], "pi_lr": [1e-3],
+                        "qf_vf_lr": [1e-3], "sample_for_eval": ["False"], "use_true_q": ["False"],
+                        "entropy_scale": [0.1, 0.01], "batch_size": [16], "buffer_size": [1000]}}
+    ej, aj = tmp_path / "Pendulum-v0.json", tmp_path / "sac.json"
+    ej.write_text(json.dumps(env)); aj.write_text(json.dumps(agent))
+    drv.main(["--env_json", str(ej), "--agent_json", str(aj), "--indices", "0", "1", "4", "--save_dir", str(tmp_path),
+              "--device_rollout", "--quiet"])
+    with open(tmp_path / "Pendulum-v0_sacresults" / "data_0_1_4.pkl", "rb") as f:
+        data = pickle.load(f)
+    assert sorted(data["experiment_data"]) == [0, 1]
+    assert [r["random_seed"] for r in data["experiment_data"][0]["runs"]] == [0, 1]
+    assert data["experiment_data"][1]["agent_params"]["entropy_scale"] == 0.01
+    run = data["experiment_data"][1]["runs"][1]
+    assert run["eval_episode_rewards"].shape == (3, 2) and run["timesteps_at_eval"].tolist() == [0, 50, 100]
+    assert run["train_episode_steps"].tolist() == [50, 50] and np.isfinite(run["eval_episode_rewards"]).all()
