@@ -1,153 +1,136 @@
-"""Train / evaluate loop (mirrors experiment.py:14-217 of the reference).
+"""Host-driven train / evaluate schedule of one run (the role of experiment.py in the reference).
 
-Semantics kept:
-  * one evaluation before any training (step 0), then one every ``eval_interval`` TRAINING steps,
-    run IN THE MIDDLE of the training episode -- which calls ``agent.reset()`` and therefore resets
-    the OU noise mid-episode (quirk Q8);
-  * a step that ends the episode exactly at EPISODE_STEPS_LIMIT is "truncated": the agent's
-    ``update`` is still called (so ``learn()`` runs) but the transition is not stored (Q7);
-    environments whose name starts with 'Bimodal1DEnv' are exempt;
-  * an episode cut by TOTAL_STEPS_LIMIT is not recorded in the per-episode lists;
-  * ``run()`` returns the same 9-tuple as the reference (experiment.py:96-98).
+``Experiment(agent, train_environment, test_environment, seed, ...).run()`` returns the 9-tuple the reference's
+driver unpacks: (train returns per episode, eval returns per evaluation, train steps per episode, eval steps per
+evaluation, training-step counts at which evaluations ran, training wall time, evaluation wall time, number of
+training episodes started, cumulative step count at the end of every recorded training episode).
+
+Schedule (each point is asserted by tests/test_experiment_host.py):
+  * evaluation number 0 runs before the first training step; afterwards one evaluation every ``eval_interval``
+    TRAINING steps, wherever in a training episode that falls -- and since every evaluation episode calls
+    ``agent.reset()``, the exploration noise of the interrupted training episode restarts (quirk Q8);
+  * a step that ends an episode exactly at EPISODE_STEPS_LIMIT is "truncated": ``agent.update`` is still called
+    (so ``learn()`` runs) with ``is_truncated=True`` and the agent drops the transition (quirk Q7); environments
+    whose name starts with 'Bimodal1DEnv' are exempt from the truncation rule;
+  * the episode that TOTAL_STEPS_LIMIT cuts short is counted as started but not recorded;
+  * the next action is requested only if the episode goes on.
 TensorBoard summaries (write_log) are not produced: TensorFlow is not a dependency here.
 """
 import time
 from datetime import datetime
 
-import numpy as np  # noqa: F401
+
+def _hms(seconds):
+    return time.strftime("%H:%M:%S", time.gmtime(seconds))
 
 
 class Experiment(object):
     def __init__(self, agent, train_environment, test_environment, seed, writer=None, write_log=False,
                  write_plot=False, verbose=True):
         self.agent = agent
-        self.train_environment = train_environment
-        self.train_environment.set_random_seed(seed)
-        self.test_environment = test_environment
-        self.test_environment.set_random_seed(seed)
-
-        self.train_rewards_per_episode = []
-        self.train_cum_steps = []
-        self.train_episodes = 0
-        self.timesteps_at_eval = []
-        self.train_steps_per_episode = []
-        self.eval_steps_per_episode = []
-        self.eval_rewards_per_episode = []
+        self.train_environment, self.test_environment = train_environment, test_environment
+        for env in (train_environment, test_environment):
+            env.set_random_seed(seed)
+        self.writer, self.write_log, self.write_plot, self.verbose = writer, write_log, write_plot, verbose
 
         self.total_step_count = 0
-        self.writer = writer
-        self.write_log = write_log
-        self.write_plot = write_plot
-        self.verbose = verbose
+        self.train_episodes = 0
+        self.train_rewards_per_episode, self.train_steps_per_episode, self.train_cum_steps = [], [], []
+        self.eval_rewards_per_episode, self.eval_steps_per_episode, self.timesteps_at_eval = [], [], []
+        self.cum_train_time = self.cum_eval_time = 0.0
 
-        self.cum_train_time = 0.0
-        self.cum_eval_time = 0.0
-
-    def _say(self, msg):
+    # ---------------------------------------------------------------------------------------------
+    def _say(self, text):
         if self.verbose:
-            print(msg)
+            print(text)
+
+    def _budget_left(self):
+        return self.total_step_count < self.train_environment.TOTAL_STEPS_LIMIT
 
     def run(self):
-        episode_count = 0
-        start_run = datetime.now()
-        self._say("Start run at: " + str(start_run) + '\n')
-
-        self.cum_eval_time += self.eval()
-        self.timesteps_at_eval.append(self.total_step_count)
-
-        while self.total_step_count < self.train_environment.TOTAL_STEPS_LIMIT:
-            t0 = time.time()
-            episode_reward, num_steps, force_terminated, eval_session_time = self.run_episode_train(is_train=True)
-            train_ep_time = time.time() - t0 - eval_session_time
-            self.cum_train_time += train_ep_time
-            self._say("Train:: ep: " + str(episode_count) + ", r: " + str(episode_reward) + ", n_steps: "
-                      + str(num_steps) + ", elapsed: " + time.strftime("%H:%M:%S", time.gmtime(train_ep_time)))
-            if not force_terminated:
-                self.train_rewards_per_episode.append(episode_reward)
+        began = datetime.now()
+        self._say("Start run at: %s\n" % began)
+        self._evaluation_point()
+        episode = 0
+        while self._budget_left():
+            tick = time.time()
+            ret, length, cut_short, eval_seconds = self.run_episode_train(is_train=True)
+            spent = time.time() - tick - eval_seconds
+            self.cum_train_time += spent
+            self._say("Train:: ep: %d, r: %s, n_steps: %d, elapsed: %s" % (episode, ret, length, _hms(spent)))
+            if not cut_short:
+                self.train_rewards_per_episode.append(ret)
+                self.train_steps_per_episode.append(length)
                 self.train_cum_steps.append(self.total_step_count)
-                self.train_steps_per_episode.append(num_steps)
-            episode_count += 1
-
+            episode += 1
         self.train_environment.close()
-        end_run = datetime.now()
-        self._say("End run at: " + str(end_run) + '\n')
-        self._say("Total Time taken: " + str(end_run - start_run) + '\n')
-        self._say("Training Time: " + time.strftime("%H:%M:%S", time.gmtime(self.cum_train_time)))
-        self._say("Evaluation Time: " + time.strftime("%H:%M:%S", time.gmtime(self.cum_eval_time)))
+        ended = datetime.now()
+        self._say("End run at: %s\n\nTotal Time taken: %s\n" % (ended, ended - began))
+        self._say("Training Time: %s\nEvaluation Time: %s" % (_hms(self.cum_train_time), _hms(self.cum_eval_time)))
+        return (self.train_rewards_per_episode, self.eval_rewards_per_episode, self.train_steps_per_episode,
+                self.eval_steps_per_episode, self.timesteps_at_eval, self.cum_train_time, self.cum_eval_time,
+                self.train_episodes, self.train_cum_steps)
 
-        return (self.train_rewards_per_episode, self.eval_rewards_per_episode,
-                self.train_steps_per_episode, self.eval_steps_per_episode,
-                self.timesteps_at_eval, self.cum_train_time, self.cum_eval_time, self.train_episodes,
-                self.train_cum_steps)
+    def _evaluation_point(self):
+        """record where the evaluation happens, run it, return its wall time"""
+        self.timesteps_at_eval.append(self.total_step_count)
+        seconds = self.eval()
+        self.cum_eval_time += seconds          # eval() adds it as well: the reference counts it twice, kept
+        return seconds
 
+    # ---------------------------------------------------------------------------------------------
     def run_episode_train(self, is_train):
-        env = self.train_environment
+        env, agent = self.train_environment, self.agent
+        limit, budget = env.EPISODE_STEPS_LIMIT, env.TOTAL_STEPS_LIMIT
+        exempt = env.name.startswith('Bimodal1DEnv')
         self.train_episodes += 1
-        eval_session_time = 0.0
-
-        obs = env.reset()
-        self.agent.reset()
-
-        episode_reward = 0.
-        done = False
-        action = self.agent.start(obs, is_train)
-        episode_step_count = 0
-
-        while not (done or episode_step_count == env.EPISODE_STEPS_LIMIT
-                   or self.total_step_count == env.TOTAL_STEPS_LIMIT):
-            episode_step_count += 1
+        state = env.reset()
+        agent.reset()
+        action = agent.start(state, is_train)
+        ret, length, done, eval_seconds = 0., 0, False, 0.0
+        while not done and length != limit and self.total_step_count != budget:
+            length += 1
             self.total_step_count += 1
-
-            obs_n, reward, done, info = env.step(action)
-            episode_reward += reward
-
-            if env.name.startswith('Bimodal1DEnv'):
-                is_truncated = False
-            else:
-                is_truncated = bool(done and episode_step_count == env.EPISODE_STEPS_LIMIT)
-
-            self.agent.update(obs, obs_n, float(reward), action, done, is_truncated)
-
+            following, reward, done, _ = env.step(action)
+            ret += reward
+            hit_limit = (not exempt) and bool(done and length == limit)
+            agent.update(state, following, float(reward), action, done, hit_limit)
             if not done:
-                action = self.agent.step(obs_n, is_train)
-            obs = obs_n
-
+                action = agent.step(following, is_train)
+            state = following
             if self.total_step_count % env.eval_interval == 0:
+                # timesteps_at_eval is appended before the evaluation, the double-counted time is not used here
                 self.timesteps_at_eval.append(self.total_step_count)
-                eval_session_time += self.eval()
+                eval_seconds += self.eval()
+        cut_short = not (done or length == limit)
+        return ret, length, cut_short, eval_seconds
 
-        force_terminated = not (done or episode_step_count == env.EPISODE_STEPS_LIMIT)
-        return episode_reward, episode_step_count, force_terminated, eval_session_time
-
+    # ---------------------------------------------------------------------------------------------
     def eval(self):
-        rewards, steps = [], []
-        eval_session_time = 0.0
-        for i in range(self.test_environment.eval_episodes):
-            t0 = time.time()
-            episode_reward, num_steps = self.run_episode_eval(self.test_environment, is_train=False)
-            elapsed = time.time() - t0
-            steps.append(num_steps)
-            rewards.append(episode_reward)
-            eval_session_time += elapsed
-            self._say("=== EVAL :: ep: " + str(i) + ", r: " + str(episode_reward) + ", n_steps: " + str(num_steps)
-                      + ", elapsed: " + time.strftime("%H:%M:%S", time.gmtime(elapsed)))
-        self.eval_rewards_per_episode.append(rewards)
-        self.eval_steps_per_episode.append(steps)
-        self.cum_eval_time += eval_session_time      # (the reference also adds it again in run(): kept)
-        return eval_session_time
+        env = self.test_environment
+        returns, lengths, total = [], [], 0.0
+        for number in range(env.eval_episodes):
+            tick = time.time()
+            ret, length = self.run_episode_eval(env, is_train=False)
+            took = time.time() - tick
+            total += took
+            returns.append(ret)
+            lengths.append(length)
+            self._say("=== EVAL :: ep: %d, r: %s, n_steps: %d, elapsed: %s" % (number, ret, length, _hms(took)))
+        self.eval_rewards_per_episode.append(returns)
+        self.eval_steps_per_episode.append(lengths)
+        self.cum_eval_time += total
+        return total
 
     def run_episode_eval(self, test_env, is_train):
-        obs = test_env.reset()
+        state = test_env.reset()
         self.agent.reset()
-        episode_reward = 0.
-        done = False
-        action = self.agent.start(obs, is_train)
-        episode_step_count = 0
-        while not (done or episode_step_count == test_env.EPISODE_STEPS_LIMIT):
-            obs_n, reward, done, info = test_env.step(action)
-            episode_reward += reward
+        action = self.agent.start(state, is_train)
+        ret, length, done = 0., 0, False
+        while not done and length != test_env.EPISODE_STEPS_LIMIT:
+            state, reward, done, _ = test_env.step(action)
+            ret += reward
+            length += 1
             if not done:
-                action = self.agent.step(obs_n, is_train)
-            obs = obs_n
-            episode_step_count += 1
-        return episode_reward, episode_step_count
+                action = self.agent.step(state, is_train)
+        return ret, length
