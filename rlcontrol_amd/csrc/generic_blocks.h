@@ -28,16 +28,24 @@ __device__ inline void blk_dense_tile4(const float* X, int ldx, int K, const flo
         gf4 acc[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[j] = gf4{0.f, 0.f, 0.f, 0.f};
+        // operands of the next 4 k are loaded before the FMAs of the current ones (activations and weights come
+        // from L2 / HBM and only four waves share a CU: the loads would otherwise sit on the critical path)
+        gf4 x[4], w[4], xn[4], wn[4];
+        auto load = [&](gf4 (&xx)[4], gf4 (&ww)[4], int k) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) xx[j] = *reinterpret_cast<const gf4*>(&X[(size_t)br[j] * ldx + k]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) ww[i] = *reinterpret_cast<const gf4*>(&W[(size_t)(k + i) * N + n0]);
+        };
+        if (K4 > 0) load(x, w, 0);
         for (int k = 0; k < K4; k += 4) {
-            gf4 x[4], w[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) x[j] = *reinterpret_cast<const gf4*>(&X[(size_t)br[j] * ldx + k]);
-#pragma unroll
-            for (int i = 0; i < 4; i++) w[i] = *reinterpret_cast<const gf4*>(&W[(size_t)(k + i) * N + n0]);
+            if (k + 4 < K4) load(xn, wn, k + 4);
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) acc[j] += x[j][i] * w[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { x[j] = xn[j]; w[j] = wn[j]; }
         }
         for (int k = K4; k < K; k++) {
             const gf4 w = *reinterpret_cast<const gf4*>(&W[(size_t)k * N + n0]);
@@ -80,18 +88,24 @@ __device__ inline void blk_bwd_input_tile4(const float* dY, int lddy, int N, con
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int i = 0; i < 4; i++) acc[j][i] = 0.0f;
+        gf4 d[4], w[4], dn[4], wn[4];
+        auto load = [&](gf4 (&dd)[4], gf4 (&ww)[4], int n) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dd[j] = *reinterpret_cast<const gf4*>(&dY[(size_t)br[j] * lddy + n]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) ww[i] = *reinterpret_cast<const gf4*>(&W[(size_t)(k0 + i) * N + n]);
+        };
+        load(d, w, 0);
         for (int n = 0; n < N; n += 4) {
-            gf4 d[4], w[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) d[j] = *reinterpret_cast<const gf4*>(&dY[(size_t)br[j] * lddy + n]);
-#pragma unroll
-            for (int i = 0; i < 4; i++) w[i] = *reinterpret_cast<const gf4*>(&W[(size_t)(k0 + i) * N + n]);
+            if (n + 4 < N) load(dn, wn, n + 4);
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
                     for (int i = 0; i < 4; i++) acc[j][i] += d[j][c] * w[i][c];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { d[j] = dn[j]; w[j] = wn[j]; }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -200,7 +214,21 @@ __device__ inline void blk_grad_adam_tile4(const float* X, int ldx, int K, const
         gf4 g[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) g[i] = gf4{0.f, 0.f, 0.f, 0.f};
-        for (int b = 0; b < B; b++) {
+        // four batch rows in flight per thread (8 loads issued before their FMAs)
+        int b = 0;
+        for (; b + 4 <= B; b += 4) {
+            gf4 x[4], d[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                x[q] = *reinterpret_cast<const gf4*>(&X[(size_t)(b + q) * ldx + k0]);
+                d[q] = *reinterpret_cast<const gf4*>(&dY[(size_t)(b + q) * lddy + n0]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) g[i] += x[q][i] * d[q];
+        }
+        for (; b < B; b++) {
             const gf4 x = *reinterpret_cast<const gf4*>(&X[(size_t)b * ldx + k0]);
             const gf4 d = *reinterpret_cast<const gf4*>(&dY[(size_t)b * lddy + n0]);
 #pragma unroll
