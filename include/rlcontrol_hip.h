@@ -251,6 +251,12 @@ int rlc_ddpg_rollout_run(rlc_ddpg* h, int64_t n_steps, int64_t* out_total_steps)
  * (sample_for_eval "False"); the N(0,1) draws come from the agent's Philox stream */
 int rlc_sac_rollout_create(rlc_sac* h, const rlc_rollout_config* cfg);
 int rlc_sac_rollout_run(rlc_sac* h, int64_t n_steps, int64_t* out_total_steps);
+/* the same loop for a NAF population (agents/NAF.py:24-75): training actions are draws from
+ * N(mu, noise_scale * pinv(L L^T)) clipped to the action bounds (naf_network.py:152-176; on the device
+ * mu + sqrt(noise_scale) L^-T z with Philox normals z), evaluation uses the greedy action.
+ * noise_scale: [n_agents] (the value naf.json sweeps) */
+int rlc_naf_rollout_create(rlc_naf* h, const rlc_rollout_config* cfg, const float* noise_scale);
+int rlc_naf_rollout_run(rlc_naf* h, int64_t n_steps, int64_t* out_total_steps);
 /* counts of one agent: finished training episodes, evaluations run, training steps taken */
 int rlc_rollout_counts(rlc_handle* h, int32_t agent, int64_t* n_train_episodes, int64_t* n_evals,
                        int64_t* total_steps);

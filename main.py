@@ -12,7 +12,7 @@ offline tooling reads identical fields).  Differences: no TensorFlow summary wri
 and ``--gpu`` picks the HIP device.
 
 ``--device_rollout`` runs ALL indices of the range concurrently as one population on the GPU with the
-environment simulated on the device (rlcontrol_amd/device_experiment.py; DDPG or SoftActorCritic on Pendulum-v0):
+environment simulated on the device (rlcontrol_amd/device_experiment.py; DDPG, SoftActorCritic or NAF on Pendulum-v0):
 same schedule, same pickle, Philox random streams instead of numpy's.
 
 Under ``python -m torch.distributed.run --nproc-per-node N main.py ...`` the INDEX range is dealt round-robin to
@@ -87,6 +87,8 @@ _SHARED_KEYS = {
              "warmup_steps", "norm_type", "exploration_policy", "ou_theta", "ou_mu", "ou_sigma"),
     "SoftActorCritic": ("actor_l1_dim", "actor_l2_dim", "critic_l1_dim", "critic_l2_dim", "batch_size", "buffer_size",
                         "tau", "gamma", "warmup_steps", "norm_type", "exploration_policy", "sample_for_eval"),
+    "NAF": ("l1_dim", "l2_dim", "batch_size", "buffer_size", "tau", "gamma", "warmup_steps", "norm_type",
+            "exploration_policy"),
 }
 
 
@@ -109,6 +111,19 @@ def _make_population(agent_name, members, arg_params):
         for i, m in enumerate(members):
             pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.shared_l1_dim, c0.actor_l2_dim,
                                           c0.critic_l2_dim, m[3].random_seed), init_target=True)
+        return pop
+    if agent_name == "NAF":
+        from rlcontrol_amd.hip_naf import NAFPopulation, init_params
+        if c0.exploration_policy != 'none':
+            raise RuntimeError("the device loop implements NAF's own covariance exploration (exploration_policy 'none')")
+        pop = NAFPopulation(
+            n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, l1_dim=c0.l1_dim, l2_dim=c0.l2_dim,
+            batch_size=c0.batch_size, buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min,
+            state_max=c0.state_max, action_max=c0.action_max, learning_rate=[m[3].learning_rate for m in members],
+            seeds=seeds, clip_state=(c0.norm_type != 'none'), device=device)
+        for i, m in enumerate(members):
+            pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.l1_dim, c0.l2_dim, m[3].random_seed),
+                           init_target=True)
         return pop
     from rlcontrol_amd.hip_sac import SACPopulation, init_params
     if c0.exploration_policy != 'none' or c0.sample_for_eval == "True" or c0.norm_type == 'none':
@@ -133,7 +148,7 @@ def run_indices_on_device(indices, agent_json, env_json, env_params, arg_params,
     from rlcontrol_amd.device_experiment import DeviceExperiment
     agent_name = agent_json['agent']
     if agent_name not in _SHARED_KEYS:
-        raise RuntimeError("--device_rollout is built for the DDPG and SoftActorCritic agents (got %r)" % agent_name)
+        raise RuntimeError("--device_rollout is built for the DDPG, SoftActorCritic and NAF agents (got %r)" % agent_name)
     groups = OrderedDict()
     for index in indices:
         agent_params, total_num_sweeps = get_sweep_parameters(agent_json['sweeps'], index)
@@ -147,7 +162,8 @@ def run_indices_on_device(indices, agent_json, env_json, env_params, arg_params,
     for members in groups.values():
         c0 = members[0][3]
         pop = _make_population(agent_name, members, arg_params)
-        exp = DeviceExperiment(pop, env_json, gamma=c0.gamma, warmup_steps=c0.warmup_steps)
+        exp = DeviceExperiment(pop, env_json, gamma=c0.gamma, warmup_steps=c0.warmup_steps,
+                               noise_scale=[m[3].noise_scale for m in members] if agent_name == "NAF" else None)
         if verbose:
             print("device rollout: %d agents, %d steps each" % (len(members), exp.total_steps_limit))
         results = exp.run(progress=progress)

@@ -19,6 +19,7 @@ from . import philox
 from .ddpg import DDPGOracle
 
 KEY_SAC_EPS = 0x9E3779B97F4A7C15     # sac_policy.h: the agent's N(0,1) stream (acting and minibatch draws)
+KEY_NAF_EPS = 0x4E41465F4E4F4953     # naf_policy.h: the N(0,1) stream of NAF's exploration draw
 
 
 class Pendulum(object):
@@ -70,7 +71,7 @@ class RolloutOracle(object):
         self.amax = np.asarray(action_max, np.float32).reshape(-1)
         f = np.float32
         self.ou_theta, self.ou_mu, self.ou_sigma = f(ou_theta), f(ou_mu), f(ou_sigma)
-        self.A = dims.A if hasattr(dims, "A") else dims.tuple()[1]
+        self.A = dims.A if hasattr(dims, "A") else dims.t[1]      # Dims has .A; SacDims / NafDims keep a tuple .t
         self.noise = np.full(self.A, self.ou_mu, np.float32)
         self.noise_ctr = 0
         self.sample_ctr = 0
@@ -213,3 +214,50 @@ class SacRolloutOracle(RolloutOracle):
         self.net.update(np.array([r[0] for r in rows]), np.array([r[1] for r in rows]),
                         np.array([r[3] for r in rows]), np.array([r[2] for r in rows]),
                         np.array([r[4] for r in rows]), eps)
+
+
+class NafRolloutOracle(RolloutOracle):
+    """One NAF agent of the on-device loop (naf_rollout_device.h): the training action is
+    mu + sqrt(noise_scale) * L^-T z (a draw from N(mu, noise_scale (L L^T)^-1), naf_network.py:152-176) clipped to
+    the action bounds, evaluation uses the greedy action."""
+
+    def __init__(self, dims, theta, lr, tau, state_min, state_max, action_max, noise_scale, seed, batch_size,
+                 buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes):
+        self._naf = (lr,)
+        self.noise_scale = np.float32(noise_scale)
+        amax = np.asarray(action_max, np.float32).reshape(-1)
+        RolloutOracle.__init__(self, dims, theta, 0.0, 0.0, tau, state_min, state_max, -amax, amax, seed, batch_size,
+                               buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes)
+
+    def _make_net(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state):
+        from .naf import NAFOracle
+        return NAFOracle(dims, theta, self._naf[0], tau, state_min, state_max, action_max, clip_state)
+
+    def agent_reset(self):
+        pass
+
+    def act(self, obs, is_train):
+        x = np.asarray(obs, np.float64).astype(np.float32).reshape(1, -1)
+        mu, lcols = self.net.act(x)
+        mu, lcols = mu[0], lcols[0]
+        if not is_train:
+            return mu
+        A, f = self.A, np.float32
+        Lm = np.zeros((A, A), np.float32)
+        p = 0
+        for c in range(A):
+            for i in range(c, A):
+                Lm[i, c] = lcols[p]
+                p += 1
+        y = np.zeros(A, np.float32)
+        sc = f(np.sqrt(self.noise_scale, dtype=np.float32))
+        for j in range(A):
+            z = philox.normal2(philox.philox4x32_10(self.seed ^ KEY_NAF_EPS, self.noise_ctr, j >> 1))[j & 1]
+            y[j] = f(sc * z)
+        for i in range(A - 1, -1, -1):
+            s = y[i]
+            for j in range(i + 1, A):
+                s = f(s - f(Lm[j, i] * y[j]))
+            y[i] = f(s / Lm[i, i])
+        self.noise_ctr += 1
+        return np.minimum(np.maximum(mu + y, self.amin), self.amax).astype(np.float32)

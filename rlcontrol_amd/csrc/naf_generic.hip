@@ -8,6 +8,7 @@
 // below-diagonal fc outputs] (naf_network.py:98-121); mu = tanh(.) * action_max per dimension.
 #include "generic_blocks.h"
 #include "naf_common.h"
+#include "naf_rollout_device.h"
 
 namespace {
 
@@ -19,6 +20,7 @@ struct NLds {
     long long* idx;
     int* pool;
     int* dups;
+    float* pol;       // scratch of the on-device training step (naf_rollout_device.h)
 };
 
 __host__ __device__ inline size_t nlds_carve(const RlcNafDims& d, unsigned char* base, NLds* out) {
@@ -43,6 +45,7 @@ __host__ __device__ inline size_t nlds_carve(const RlcNafDims& d, unsigned char*
     for (auto p : pb) *p = (float*)take(sizeof(float) * B);
     L.pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     L.dups = (int*)take(sizeof(int) * 4);
+    L.pol = (float*)take(sizeof(float) * (naf_policy_lds_floats(d) + 4));
     if (out) *out = L;
     return off;
 }
@@ -71,7 +74,8 @@ __device__ inline void naf_forward(const RlcNafDims& d, const float* th, const f
 }
 
 __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, int first_agent, int n_updates, int source,
-                                                                  const long long* host_idx, int grad_taps) {
+                                                                  const long long* host_idx, int grad_taps,
+                                                                  const RlcNafRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcNafDims d = dv.d;
     const int S = d.S, A = d.A, L1 = d.L1, L2 = d.L2, B = d.B, NN = d.NN;
@@ -91,6 +95,10 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
     float* tapg = grad_taps ? dv.tap_g + (size_t)agent * d.Ppad : nullptr;
 
     for (int u = 0; u < n_updates; u++) {
+        if (rollout) {
+            // on-device experiment loop: one environment step first; update when learn() would run
+            if (!rlc_naf_train_step_device(rollout, agent, L.pol)) continue;
+        }
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
             const unsigned long long call = dv.rep.sample_ctr[agent];
@@ -218,40 +226,57 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_act_kernel(RlcNafDev dv, int
                                                                float* mu_out, float* lcols_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcNafDims d = dv.d;
-    const int S = d.S, A = d.A, L1 = d.L1, L2 = d.L2, NN = d.NN, NL = A * (A + 1) / 2;
+    const int S = d.S, A = d.A, NL = A * (A + 1) / 2;
     const int agent = first_agent + blockIdx.x, tid = threadIdx.x;
-    float* x = (float*)smem;
-    float* h1 = x + ((S + 3) & ~3);
-    float* ha = h1 + ((L1 + 3) & ~3);
-    float* z = ha + ((L2 + 3) & ~3);          // [A]
-    float* dpre = z + RLC_NAF_MAX_A;           // [A]
-    float* npre = dpre + RLC_NAF_MAX_A;        // [NN]
+    const NafPolicyLds L = naf_policy_carve(d, (float*)smem);
     const float* th = dv.theta + (size_t)agent * d.Ppad;
     for (int i = tid; i < S; i += kThreads)
-        x[i] = clip_state_val(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin[i], dv.smax[i]);
-    __syncthreads();
-    blk_dense(x, S, S, nullptr, 0, th + d.W1, th + d.b1, L1, h1, L1, 1, 1);
-    __syncthreads();
-    blk_dense(h1, L1, L1, nullptr, 0, th + d.Wa2, th + d.ba2, L2, ha, L2, 1, 1);
-    for (int c = 0; c < A; c++) blk_dense(h1, L1, L1, nullptr, 0, th + d.Wd[c], th + d.bd[c], 1, dpre + c, A, 1, 0);
-    {
-        int off = 0;
-        for (int c = 0; c < A - 1; c++) {
-            blk_dense(h1, L1, L1, nullptr, 0, th + d.Wn[c], th + d.bn[c], A - 1 - c, npre + off, NN, 1, 0);
-            off += A - 1 - c;
-        }
+        L.x[i] = clip_state_val(states[(size_t)blockIdx.x * S + i], dv.clip_state, dv.smin[i], dv.smax[i]);
+    naf_policy_forward(d, th, L, dv.amax);
+    if (tid < A) mu_out[(size_t)blockIdx.x * A + tid] = L.out[tid];
+    if (tid == 0 && lcols_out) {
+        int p = 0;
+        for (int c = 0; c < A; c++)
+            for (int i = c; i < A; i++) lcols_out[(size_t)blockIdx.x * NL + p++] = naf_l_entry(d, L, i, c);
+    }
+}
+
+// evaluation of the on-device loop: one greedy test episode per workgroup (run_episode_eval, experiment.py:163-196)
+__global__ __launch_bounds__(kThreads) void rlc_naf_eval_kernel(RlcNafDev dv, RlcEnvDev env, int eval_round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double sim[RLC_ENV_STATE];
+    __shared__ double obs[8];
+    __shared__ int s_done;
+    const RlcNafDims d = dv.d;
+    const int S = d.S;
+    const int agent = blockIdx.x / env.eval_episodes, ep = blockIdx.x % env.eval_episodes;
+    const int tid = threadIdx.x;
+    const NafPolicyLds L = naf_policy_carve(d, (float*)smem);
+    const float* th = dv.theta + (size_t)agent * d.Ppad;
+    if (tid == 0) {
+        env_reset(env.env_id, sim, obs, dv.rep.seed[agent] ^ RLC_KEY_ENV_TEST,
+                  (unsigned long long)eval_round * env.eval_episodes + ep);
+        s_done = 0;
     }
     __syncthreads();
-    blk_dense(ha, L2, L2, nullptr, 0, th + d.Wa3, th + d.ba3, A, z, A, 1, 0);
-    __syncthreads();
-    if (tid < A) mu_out[(size_t)blockIdx.x * A + tid] = tanhf(z[tid]) * dv.amax[tid];
-    if (tid == 0 && lcols_out) {
-        int p = 0, off = 0;
-        for (int c = 0; c < A; c++) {
-            lcols_out[(size_t)blockIdx.x * NL + p++] = expf(fminf(fmaxf(dpre[c], -5.0f), 5.0f));
-            for (int k = 0; k < A - 1 - c; k++) lcols_out[(size_t)blockIdx.x * NL + p++] = npre[off + k];
-            off += A - 1 - c;
+    double ret = 0.0;
+    int steps = 0;
+    while (steps < env.episode_limit) {
+        for (int i = tid; i < S; i += kThreads) L.x[i] = clip_state_val((float)obs[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+        naf_policy_forward(d, th, L, dv.amax);
+        if (tid == 0) {
+            double reward;
+            s_done = env_step(env.env_id, sim, L.out, obs, &reward, steps + 1, env.episode_limit);
+            ret += reward;
         }
+        steps++;
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (tid == 0 && eval_round < env.max_evals) {
+        const size_t at = ((size_t)agent * env.max_evals + eval_round) * env.eval_episodes + ep;
+        env.eval_ret[at] = ret;
+        env.eval_len[at] = steps;
     }
 }
 
@@ -260,21 +285,28 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_act_kernel(RlcNafDev dv, int
 size_t rlc_naf_scratch_floats(const RlcNafDims& d) { return (size_t)d.B * (2 * (size_t)d.L1 + 4 * (size_t)d.L2); }
 
 int rlc_launch_naf_update(const RlcNafDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                          const long long* idx_dev, int grad_taps, hipStream_t st) {
+                          const long long* idx_dev, int grad_taps, hipStream_t st, const RlcNafRollout* rollout) {
     const size_t lds = nlds_carve(dv.d, nullptr, nullptr);
     RLC_REQUIRE(lds <= 64 * 1024, "NAF kernel needs %zu B of LDS (> 64 KiB)", lds);
     hipLaunchKernelGGL(rlc_naf_update_kernel, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates, source,
-                       idx_dev, grad_taps);
+                       idx_dev, grad_taps, rollout);
     RLC_HIP(hipGetLastError());
     return 0;
 }
 
 int rlc_launch_naf_act(const RlcNafDev& dv, int first_agent, int n, const float* states_dev, float* mu_dev,
                        float* lcols_dev, hipStream_t st) {
-    const size_t lds = sizeof(float) * (((dv.d.S + 3) & ~3) + ((dv.d.L1 + 3) & ~3) + ((dv.d.L2 + 3) & ~3) +
-                                        2 * RLC_NAF_MAX_A + (dv.d.NN > 0 ? dv.d.NN : 1) + 4);
+    const size_t lds = sizeof(float) * naf_policy_lds_floats(dv.d);
     hipLaunchKernelGGL(rlc_naf_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, mu_dev,
                        lcols_dev);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
+int rlc_launch_naf_eval(const RlcNafDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st) {
+    const size_t lds = sizeof(float) * naf_policy_lds_floats(dv.d);
+    hipLaunchKernelGGL(rlc_naf_eval_kernel, dim3(dv.n_agents * env.eval_episodes), dim3(kThreads), lds, st, dv, env,
+                       eval_round);
     RLC_HIP(hipGetLastError());
     return 0;
 }

@@ -134,6 +134,7 @@ int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, 
     memset(&h->env, 0, sizeof(h->env));
     h->rollout_dev = nullptr;
     h->sac_rollout_dev = nullptr;
+    h->naf_rollout_dev = nullptr;
     h->ro_total_limit = h->ro_eval_interval = h->ro_steps = h->ro_evals = 0;
     h->ro_pending_q8 = 0;
     h->st = nullptr;

@@ -3,6 +3,7 @@
 // evaluation); all per-agent state lives on the GPU (rollout_kernels.hip).
 #include "rlc_handle.h"
 #include "sac_rollout_device.h"
+#include "naf_rollout_device.h"
 
 #define RLC_NEED_DDPG(h) RLC_REQUIRE((h) && (h)->algo == RLC_ALGO_DDPG, "handle is not a DDPG population")
 #define RLC_NEED_ENV(h) RLC_REQUIRE((h) && (h)->has_env, "no rollout configured on this handle (rlc_ddpg_rollout_create)")
@@ -87,16 +88,38 @@ int rlc_sac_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
     return 0;
 }
 
-// the schedule of experiment.py:52-161 for either algorithm
+int rlc_naf_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg, const float* noise_scale) {
+    RLC_REQUIRE(h && cfg && noise_scale, "null argument");
+    RLC_REQUIRE(h->algo == RLC_ALGO_NAF, "handle is not a NAF population");
+    if (rollout_alloc(h, cfg)) return 1;
+    const size_t NA = h->naf.n_agents;
+    float* ns_dev;
+    unsigned long long* ctr_dev;
+    if (rlc_h_malloc(h, &ns_dev, NA) || rlc_h_malloc(h, &ctr_dev, NA) || rlc_h_malloc(h, &h->naf_rollout_dev, 1)) return 1;
+    for (size_t i = 0; i < NA; i++) RLC_REQUIRE(noise_scale[i] >= 0.0f, "negative noise_scale");
+    RLC_HIP(hipMemcpyAsync(ns_dev, noise_scale, NA * sizeof(float), hipMemcpyHostToDevice, h->st));
+    RlcNafRollout ro;
+    ro.dv = h->naf;
+    ro.env = h->env;
+    ro.noise_scale = ns_dev;
+    ro.noise_ctr = ctr_dev;
+    RLC_HIP(hipMemcpyAsync(h->naf_rollout_dev, &ro, sizeof(ro), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    h->has_env = true;
+    return 0;
+}
+
+// the schedule of experiment.py:52-161 for any of the algorithms
 static int rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
     if (rlc_h_use_device(h)) return 1;
     RLC_REQUIRE(n_steps >= 0, "negative n_steps");
-    const bool sac = h->algo == RLC_ALGO_SAC;
+    const bool sac = h->algo == RLC_ALGO_SAC, naf = h->algo == RLC_ALGO_NAF;
     auto eval_now = [&]() -> int {
         if (h->env.eval_episodes > 0) {
-            if (sac ? rlc_launch_sac_eval(h->sac, h->env, (int)h->ro_evals, h->st)
-                    : rlc_launch_ddpg_eval(h->dv, h->env, (int)h->ro_evals, h->st))
-                return 1;
+            const int rc = sac ? rlc_launch_sac_eval(h->sac, h->env, (int)h->ro_evals, h->st)
+                           : naf ? rlc_launch_naf_eval(h->naf, h->env, (int)h->ro_evals, h->st)
+                                 : rlc_launch_ddpg_eval(h->dv, h->env, (int)h->ro_evals, h->st);
+            if (rc) return 1;
         }
         h->ro_evals += 1;
         return 0;
@@ -104,7 +127,7 @@ static int rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps)
     if (h->ro_steps == 0 && h->ro_evals == 0)          // experiment.py:57-58: evaluate before any training
         if (eval_now()) return 1;
     // one launch per stretch between evaluations (experiment.py:131-133); kMaxPerLaunch bounds a launch's run time
-    const long long kMaxPerLaunch = sac ? 500 : 2000;
+    const long long kMaxPerLaunch = (sac || naf) ? 500 : 2000;
     long long todo = n_steps;
     if (todo > h->ro_total_limit - h->ro_steps) todo = h->ro_total_limit - h->ro_steps;
     while (todo > 0) {
@@ -114,6 +137,10 @@ static int rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps)
         if (sac) {
             if (rlc_launch_sac_update(h->sac, 0, h->sac.n_agents, (int)n, RLC_SRC_REPLAY_DEVICE_SAMPLER, nullptr, nullptr, 0,
                                       h->st, h->sac_rollout_dev))
+                return 1;
+        } else if (naf) {
+            if (rlc_launch_naf_update(h->naf, 0, h->naf.n_agents, (int)n, RLC_SRC_REPLAY_DEVICE_SAMPLER, nullptr, 0, h->st,
+                                      h->naf_rollout_dev))
                 return 1;
         } else if (launch_steps(h, (int)n, h->ro_pending_q8)) {
             return 1;
@@ -143,6 +170,12 @@ int rlc_ddpg_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_step
 int rlc_sac_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
     RLC_NEED_ENV(h);
     RLC_REQUIRE(h->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population");
+    return rollout_run(h, n_steps, out_total_steps);
+}
+
+int rlc_naf_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
+    RLC_NEED_ENV(h);
+    RLC_REQUIRE(h->algo == RLC_ALGO_NAF, "handle is not a NAF population");
     return rollout_run(h, n_steps, out_total_steps);
 }
 

@@ -33,6 +33,7 @@ struct rlc_handle {
     RlcEnvDev env;
     RlcRollout* rollout_dev;             // device copy of {dv, env}: argument block of the fused step launches
     struct RlcSacRollout* sac_rollout_dev;   // same for a SoftActorCritic population
+    struct RlcNafRollout* naf_rollout_dev;   // same for a NAF population
     long long ro_total_limit, ro_eval_interval, ro_steps, ro_evals;
     int ro_pending_q8;                   // an evaluation ran after the last update: next step resets OU after acting
 };

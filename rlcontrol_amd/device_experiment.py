@@ -1,8 +1,9 @@
 """Experiment.run() of the reference (experiment.py:52-217) for a whole population, environment on the GPU.
 
 ``DeviceExperiment(population, env_params, gamma, warmup_steps)`` drives the C ABI's rollout block
-(include/rlcontrol_hip.h): every agent of a ``DDPGPopulation`` (act + OU noise) or ``SACPopulation``
-(reparameterised sample of the policy) runs its own train / evaluate loop on the device -- act, Pendulum step,
+(include/rlcontrol_hip.h): every agent of a ``DDPGPopulation`` (act + OU noise), ``SACPopulation``
+(reparameterised sample of the policy) or ``NAFPopulation`` (draw from N(mu, noise_scale (L L^T)^-1)) runs its
+own train / evaluate loop on the device -- act, Pendulum step,
 replay insert, gated fused update, periodic greedy evaluation -- with no host round trip per step.  ``run()`` returns, per agent, the reference's 9-tuple
 (train_rewards_per_episode, eval_rewards_per_episode, train_steps_per_episode, eval_steps_per_episode,
 timesteps_at_eval, cum_train_time, cum_eval_time, train_episodes, train_cum_steps).
@@ -22,7 +23,7 @@ from ._lib import check, dptr, iptr
 
 
 class DeviceExperiment(object):
-    def __init__(self, population, env_params, gamma=0.99, warmup_steps=0, max_train_episodes=None):
+    def __init__(self, population, env_params, gamma=0.99, warmup_steps=0, max_train_episodes=None, noise_scale=None):
         name = env_params['environment']
         if name not in _lib.ENV_IDS:
             raise RuntimeError("environment %r is not simulated on the device (built in: %s)"
@@ -45,8 +46,17 @@ class DeviceExperiment(object):
         cfg.max_train_episodes = int(max_train_episodes)
         cfg.gamma = float(gamma)
         self._max_ep = int(max_train_episodes)
-        self._prefix = "rlc_sac" if type(population).__name__ == "SACPopulation" else "rlc_ddpg"
-        check(getattr(population._lib, self._prefix + "_rollout_create")(population._h, ctypes.byref(cfg)))
+        kind = type(population).__name__
+        self._prefix = {"SACPopulation": "rlc_sac", "NAFPopulation": "rlc_naf"}.get(kind, "rlc_ddpg")
+        create = getattr(population._lib, self._prefix + "_rollout_create")
+        if self._prefix == "rlc_naf":
+            if noise_scale is None:
+                raise ValueError("a NAF population needs noise_scale (per agent or one value)")
+            self._ns = np.ascontiguousarray(np.broadcast_to(np.asarray(noise_scale, np.float32).reshape(-1),
+                                                            (population.n_agents,)))
+            check(create(population._h, ctypes.byref(cfg), self._ns.ctypes.data_as(ctypes.POINTER(ctypes.c_float))))
+        else:
+            check(create(population._h, ctypes.byref(cfg)))
         self.total_steps = 0
         self.wall = 0.0
 

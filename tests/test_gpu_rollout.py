@@ -275,3 +275,44 @@ def test_main_device_rollout_sac_pickle(hip_lib, tmp_path):
     run = data["experiment_data"][1]["runs"][1]
     assert run["eval_episode_rewards"].shape == (3, 2) and run["timesteps_at_eval"].tolist() == [0, 50, 100]
     assert run["train_episode_steps"].tolist() == [50, 50] and np.isfinite(run["eval_episode_rewards"]).all()
+
+
+@pytest.mark.parametrize("noise", [0.3, 1.0])
+def test_naf_rollout_matches_cpu_restatement(hip_lib, noise):
+    """The on-device loop for a NAF population (naf_rollout_device.h) against oracle/rollout.py's NafRolloutOracle
+    on the same Philox streams."""
+    from oracle.naf import NafDims, init_params
+    from oracle.rollout import NafRolloutOracle
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    from rlcontrol_amd.hip_naf import NAFPopulation
+    dims, B, seeds, lr = (3, 1, 32, 32), 16, [8, 123456789012], [1e-3, 3e-4]
+    pop = NAFPopulation(2, *dims, B, 4096, 0.01, SMIN, SMAX, AMAX, lr, seeds=seeds)
+    d = NafDims(*dims)
+    thetas = [init_params(d, 40 + i) for i in range(2)]
+    for i in range(2):
+        pop.set_params(i, thetas[i], init_target=True)
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00009, "EpisodeSteps": 25,
+           "EvalIntervalMilSteps": 0.00004, "EvalEpisodes": 2}
+    exp = DeviceExperiment(pop, env, gamma=0.99, warmup_steps=0, noise_scale=noise)
+    exp.advance(50)
+    exp.advance(1000)
+    assert exp.total_steps == 90
+    res = exp.results()
+    for a in range(2):
+        orc = NafRolloutOracle(d, thetas[a], lr[a], 0.01, SMIN, SMAX, AMAX, noise, seeds[a], B, 4096, 0.99, 0, 25, 90, 40,
+                               2).run()
+        tr, er, tl, el, ts, _, _, n_started, tc = res[a]
+        assert tl == orc.train_len == [25] * 3 and tc == orc.train_cum == [25, 50, 75]
+        assert ts == orc.timesteps_at_eval == [0, 40, 80] and el == orc.eval_len and n_started == 4
+        assert pop.replay_size(a) == len(orc.replay) == 87
+        s, act, r, s2, g = pop.replay_gather(a, np.arange(87))
+        os_ = np.array([t[0] for t in orc.replay]); oa = np.array([t[1] for t in orc.replay])
+        pre = B + 1
+        assert np.allclose(s[:pre], os_[:pre], atol=2e-6) and np.allclose(act[:pre], oa[:pre], atol=1e-5)
+        assert np.allclose(s, os_, atol=5e-3) and np.allclose(act, oa, atol=5e-3)
+        assert (np.abs(act) <= 2.0).all() and np.std(act - np.clip(oa, -2, 2)) < 1e-2
+        assert np.allclose(er[0], orc.eval_ret[0], rtol=1e-5, atol=1e-4)
+        assert np.allclose(er, orc.eval_ret, rtol=5e-3, atol=5e-2)
+        th = pop.get_blob(a, "theta")
+        assert np.max(np.abs(th - orc.net.theta)) < 5e-3 * np.max(np.abs(orc.net.theta))
+    pop.close()
