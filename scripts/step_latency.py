@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Single-agent drop-in path: wall time per environment step (replay_add + fused update + act round trip)."""
 import os, sys, time
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from test_gpu_agent import _config  # noqa

@@ -4,7 +4,7 @@ import os
 import sys
 
 import numpy as np
-import torch
+import torch  # noqa: F401  (initialises torch.distributed before the spawned workers import it)
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
