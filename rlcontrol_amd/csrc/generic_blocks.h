@@ -6,7 +6,7 @@
 
 namespace gen {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 1024;
 constexpr int kRows = 4;   // batch rows per thread-item in the dense loops
 
 typedef float gf4 __attribute__((ext_vector_type(4)));
