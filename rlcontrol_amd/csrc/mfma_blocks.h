@@ -1,0 +1,681 @@
+// mfma_blocks.h -- gfx950 fp32 matrix-core (v_mfma_f32_16x16x4_f32) building blocks shared by the fused DDPG,
+// SoftActorCritic and NAF update kernels (ddpg_mfma_kernel.h, sac_mfma_kernel.h, naf_mfma_kernel.h).
+//
+// One workgroup of 512 threads (8 waves, two per SIMD) owns one agent.  Everything [B, H]-sized stays on the CU:
+//
+//   LDS   hbuf   fp32 [MT*16][LDH]   the activation that feeds a 16-deep-chunked contraction: A operand of every
+//                                    forward GEMM and B operand of the weight-gradient GEMMs
+//         mask   u8   [MT*16][MSTRIDE]  relu masks of the hidden layers, one BYTE per (row, unit); a byte can hold
+//                                    several masks as bit planes (SAC: pi / Q, NAF: mu / V branch), so that
+//                                    d(hidden) = mask * (seed . wvec) -- a rank-NS outer product -- is regenerated on
+//                                    the fly as an MFMA operand instead of being stored as [B,H] fp32
+//         part   fp32 [8][MT*16][NJ]  per-wave partials of reductions over features, summed in a fixed order
+//         wvec   fp32 [NS][256]       the staged output-layer weights that turn seeds into d(hidden)
+//   VGPR  accumulators of the GEMM in flight (MT x NTW tiles of 16x16), weight fragments streamed
+//         global -> VGPR (each weight element is read once per GEMM per agent; no LDS staging)
+//   HBM   weights, target weights, Adam m/v: the big matrices are updated (Adam + Polyak) in the epilogue of their
+//         weight-gradient GEMM straight from the accumulators
+//
+// Tiling: batch rows on the MFMA M axis (MT = ceil(B/16) tiles), features on N; wave w of 8 owns the ADJACENT
+// N tiles NTW*w .. NTW*w+NTW-1 for ALL M tiles, so reductions over the batch (bias / output-layer / first-layer
+// gradients) are wave-local and only reductions over features cross waves through LDS partials, summed in a fixed
+// order (deterministic: K updates in one launch == K launches, bit for bit).
+// fp32 in / fp32 accumulate MFMA is a k-ordered fmaf chain (exact fp32), so the 1e-5 parity bar holds.
+//
+// Big matrices use the TILE-BLOCKED layout of rlc_common.h (rlc_blk_index): every instruction of the weight
+// streams touches 1 KB contiguous.
+#pragma once
+#include <type_traits>
+
+#include "rlc_common.h"
+
+namespace mfb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Every LDS pointer is typed with its address space: hipcc's address-space inference loses pointers that travel
+// through structs and lambdas and then emits flat_load / flat_store (measured: 9 % of the DDPG update).
+#define RLC_LDS __attribute__((address_space(3)))
+typedef RLC_LDS float lds_f32;
+typedef RLC_LDS f32x4 lds_f32x4;
+typedef RLC_LDS unsigned char lds_u8;
+typedef RLC_LDS unsigned int lds_u32;
+typedef RLC_LDS int lds_i32;
+typedef RLC_LDS double lds_f64;
+typedef RLC_LDS long long lds_i64;
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;     // two waves per SIMD: one can issue MFMA while the other does VALU / waits on loads
+constexpr int SMAX = 8;       // state rows are padded to 8 floats in LDS (two ds_read_b128)
+
+// Row stride (bytes) of the byte masks for NT16 N tiles: 4*odd dwords, so that the dword a lane reads in the
+// backward GEMM (row 16mt+c, bytes nc+4g..+3) sits in bank (4*odd*c + g + const) mod 64: conflict-free for all lanes.
+constexpr int mask_stride(int nt16) { return ((nt16 + 1) & 1) ? 16 * (nt16 + 1) : 16 * (nt16 + 2); }
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// sum over the 16 lanes that share lane>>4 (rotate-reduce with DPP row_ror: every lane gets the sum)
+template <int ROR>
+__device__ __forceinline__ float dpp_ror_add(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + ROR, 0xf, 0xf, false);
+    return x + __int_as_float(y);
+}
+__device__ __forceinline__ float row16_sum(float x) {
+    x = dpp_ror_add<8>(x);
+    x = dpp_ror_add<4>(x);
+    x = dpp_ror_add<2>(x);
+    x = dpp_ror_add<1>(x);
+    return x;
+}
+// sum over the 4 lane groups (lanes l, l+16, l+32, l+48)
+__device__ __forceinline__ float col4_sum(float x) {
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+__host__ __device__ inline int ldh_for(int H1) {
+    // leading dimension with (LDH/4) % 16 == 2: conflict-free ds_read_b128 rows AND b32 columns
+    int q = (H1 + 3) / 4;
+    while ((q & 15) != 2) q++;
+    return q * 4;
+}
+
+struct BlkLds {
+    lds_f32* hbuf;
+    lds_u8* mask;
+};
+
+struct NoExtra {};
+
+// MT: M tiles (batch rows / 16); NTW: N tiles per wave (1: widths <= 128, 2: widths <= 256); MSTRIDE: mask row bytes
+template <int MT, int NTW, int MSTRIDE>
+struct Blk {
+    static constexpr int MB = MT * 16;
+
+    // per-thread geometry
+    int tid, lane, wave, c, g;
+    int S, H1, B, LDH;      // H1 = width of the activation held in hbuf (k-dim of the forward GEMMs)
+    BlkLds L;
+#ifdef RLC_STAMPS
+    float* stamp_buf = nullptr;
+    long long t_sub = 0;
+    __device__ __forceinline__ void sub_begin() { if (tid == 0) t_sub = clock64(); }
+    __device__ __forceinline__ void sub_stamp(int i) {
+        if (tid == 0 && stamp_buf) { const long long t = clock64(); stamp_buf[i] += (float)(t - t_sub); t_sub = t; }
+    }
+#else
+    __device__ __forceinline__ void sub_begin() {}
+    __device__ __forceinline__ void sub_stamp(int) {}
+#endif
+
+    __device__ __forceinline__ void init_geometry() {
+        tid = threadIdx.x; lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        c = lane & 15; g = lane >> 4;
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
+    // ---------------------------------------------------------------------------------------
+    __device__ __forceinline__ void trunk(const float* W1, const float* b1, const lds_f32* xs) {
+        if (S <= 4) trunk_t<4>(W1, b1, xs);      // wave-uniform: Pendulum-sized states need one 16-byte read per row
+        else trunk_t<SMAX>(W1, b1, xs);
+    }
+    template <int SP>
+    __device__ __forceinline__ void trunk_t(const float* W1, const float* b1, const lds_f32* xs) {
+        // 256 column slots x 2 row halves
+        const int half = tid >> 8;
+        for (int k = tid & 255; k < LDH; k += 256) {
+            float w[SP];
+            float bias = 0.0f;
+            const bool live = k < H1;
+#pragma unroll
+            for (int i = 0; i < SP; i++) w[i] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
+            if (live) bias = b1[k];
+#pragma unroll 4
+            for (int b = half * (MB / 2); b < (half + 1) * (MB / 2); b++) {
+                const f32x4 x0 = *reinterpret_cast<const lds_f32x4*>(&xs[b * SMAX]);
+                float acc = 0.0f;      // same i-order as the scalar form; padded lanes multiply by w = 0
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc += x0[i] * w[i];
+                if (SP > 4) {
+                    const f32x4 x1 = *reinterpret_cast<const lds_f32x4*>(&xs[b * SMAX + 4]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc += x1[i] * w[(SP > 4 ? 4 : 0) + i];
+                }
+                acc = fmaxf(acc + bias, 0.0f);
+                L.hbuf[b * LDH + k] = (live && b < B) ? acc : 0.0f;
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // forward GEMM: acc[mt][i] (tile rows 16mt.., cols 16*(NTW*wave+i)..) = hbuf[:, 0:K] . W[0:K, :]
+    // A: one ds_read_b128 per M tile per 16-deep chunk, lane (c,g) holds k = kc+4g+s for step s;
+    // B: tile-blocked W (rlc_blk_index): block (kc/16, t) holds rows kc..kc+15 of tile t; this lane needs rows
+    //    4g+s of column c -> four dwords 16 B apart inside the block's 1 KB, streamed global -> VGPR.
+    // No masks anywhere in the loop: blocks are zero-padded to 16x16 in memory (rows K..16*ceil(K/16)-1 are
+    // zeros -- a critic's action rows live in their own block row), hbuf columns >= H1 are zeros or
+    // finite neighbours (times a zero weight), and the number of tiles a wave owns is a template
+    // parameter.  Two register sets (A and B fragments of the chunk in flight / the next chunk) alternate in a
+    // loop unrolled by two, so there are no register-rotation moves either: per chunk a wave issues
+    // MT ds_read_b128 + 4*NOWN global_load_dword + 4*MT*NOWN MFMAs and little else.
+    // ---------------------------------------------------------------------------------------
+    template <int NOWN>
+    __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB) {
+        const float* wp = W + ((size_t)(NTW * wave) << 8) + (((((c >> 2) << 4) + 4 * g) << 2) + (c & 3));
+        const size_t wstep = (size_t)NT << 8;                       // floats between block rows
+        const lds_f32* ap = L.hbuf + c * LDH + 4 * g;
+        f32x4 a0[MT], a1[MT];
+        float b0[NOWN][4], b1[NOWN][4];
+        auto loadA = [&](f32x4 (&dst)[MT], int ch) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const lds_f32x4*>(ap + 16 * mt * LDH + 16 * ch);
+        };
+        auto loadB = [&](float (&dst)[NOWN][4], int ch) {
+#pragma unroll
+            for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) dst[i][s] = wp[(size_t)ch * wstep + (i << 8) + 4 * s];
+        };
+        auto mac = [&](const f32x4 (&a)[MT], const float (&b)[NOWN][4]) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(a[mt][s], b[i][s], acc[mt][i]);
+        };
+        loadB(b0, 0);
+        loadA(a0, 0);
+        int ch = 0;
+        for (; ch + 2 <= KB; ch += 2) {
+            loadB(b1, ch + 1);
+            loadA(a1, ch + 1);
+            mac(a0, b0);
+            if (ch + 2 < KB) {          // wave-uniform
+                loadB(b0, ch + 2);
+                loadA(a0, ch + 2);
+            }
+            mac(a1, b1);
+        }
+        if (ch < KB) mac(a0, b0);      // odd chunk count: the last chunk is already loaded
+    }
+
+    __device__ __forceinline__ void fwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int N, int K) {
+        const int NT = (N + 15) >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef RLC_STAMPS
+        const long long t_w0 = clock64();
+#endif
+        const int nown = NT - NTW * wave;          // tiles this wave owns: wave-uniform
+        const int KB = (K + 15) >> 4;
+        if constexpr (NTW >= 2) {
+            if (nown >= 2) fwd_loop<2>(acc, W, NT, KB);
+            else if (nown == 1) fwd_loop<1>(acc, W, NT, KB);
+        } else {
+            if (nown >= 1) fwd_loop<1>(acc, W, NT, KB);
+        }
+#ifdef RLC_STAMPS
+        if (lane == 0 && stamp_buf) stamp_buf[48 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
+#endif
+    }
+
+    // acc = relu(acc + bias[n] + sum_j E[b][j] * Wx[xrow0+j][n])        (E = extra input columns of a concat layer)
+    template <int NE>
+    __device__ __forceinline__ void bias_relu(f32x4 (&acc)[MT][NTW], const float* bias, int N, const lds_f32* E = nullptr,
+                                              const float* Wx = nullptr /* tile-blocked matrix whose rows xrow0+j multiply E */,
+                                              int xrow0 = 0) {
+        const int NT = (N + 15) >> 4;
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = NTW * wave + i;
+            const int n = 16 * t + c;
+            const bool ok = t < NT && n < N;
+            const float bs = ok ? bias[n] : 0.0f;
+            float wx[NE > 0 ? NE : 1];
+#pragma unroll
+            for (int j = 0; j < NE; j++) wx[j] = ok ? Wx[rlc_blk_index(xrow0 + j, n, N)] : 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = acc[mt][i][r] + bs;
+                    if (NE > 0) {
+                        const int b = 16 * mt + 4 * g + r;
+#pragma unroll
+                        for (int j = 0; j < NE; j++) v += E[b * NE + j] * wx[j];
+                    }
+                    acc[mt][i][r] = ok ? fmaxf(v, 0.0f) : 0.0f;
+                }
+        }
+    }
+
+    // part[wave][b][j] = sum over this wave's columns n of f(acc[b][n]) * cf(n, j); f = identity or step.
+    // cf is only evaluated for valid columns.
+    template <bool STEP, int NJ, class CF>
+    __device__ __forceinline__ void row_dot(const f32x4 (&acc)[MT][NTW], int N, CF cf, lds_f32* part) {
+        const int NT = (N + 15) >> 4;
+        float co[NTW][NJ];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = NTW * wave + i;
+            const int n = 16 * t + c;
+            const bool ok = t < NT && n < N;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) co[i][j] = ok ? cf(n, j) : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    float p = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < NTW; i++) {
+                        const float v = acc[mt][i][r];
+                        p += STEP ? (v > 0.0f ? co[i][j] : 0.0f) : v * co[i][j];
+                    }
+                    p = row16_sum(p);
+                    if (c == 0) part[((size_t)wave * MB + 16 * mt + 4 * g + r) * NJ + j] = p;
+                }
+    }
+
+    // fixed-order sum of the waves' partials
+    template <int NJ>
+    __device__ __forceinline__ float part_sum(const lds_f32* part, int b, int j) const {
+        float s = part[((size_t)0 * MB + b) * NJ + j];
+#pragma unroll
+        for (int w = 1; w < kWaves; w++) s += part[((size_t)w * MB + b) * NJ + j];
+        return s;
+    }
+
+    // relu masks of the accumulators -> bit plane BIT of one byte per (row, unit).  OVERWRITE: the byte becomes
+    // the mask of this plane alone (other planes cleared); otherwise the plane is OR-ed in (the same thread owns
+    // the same byte for every plane: no race).
+    template <int BIT, bool OVERWRITE>
+    __device__ __forceinline__ void store_masks(const f32x4 (&acc)[MT][NTW], int N) {
+        const int NT = (N + 15) >> 4;
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = NTW * wave + i;
+            if (t < NT) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        lds_u8* p = &L.mask[(16 * mt + 4 * g + r) * MSTRIDE + 16 * t + c];
+                        const unsigned char bit = acc[mt][i][r] > 0.0f ? (unsigned char)(1u << BIT) : (unsigned char)0;
+                        if (OVERWRITE) *p = bit;
+                        else *p = (unsigned char)((*p & ~(1u << BIT)) | bit);
+                    }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // backward-to-input GEMM: acc[b][k'] (+)= sum_n D[b][n] * W[k'][n],  D[b][n] = mask(b,n) * sum_j seed[b][j]*wv[j][n]
+    // (D is never materialised).  k-dim = n in chunks of 16 with lane (c,g) taking n = nc+4g+s:
+    //   B = the lane's 16 bytes of block (t, nc/16) of the tile-blocked W: 1 KB contiguous per instruction;
+    //   A = the relu mask bytes of row 16mt+c (one ds_read_b32 -> four v_cvt_f32_ubyte).
+    // NS == 1 without accumulation: D is rank one, so the seed leaves the loop --
+    //   acc[b][k'] = seed[b] * sum_n maskf(b,n) * (wv[n] W[k'][n]):  A = the 0/1 mask floats as they are, B is
+    //   scaled by wv (4 multiplies per tile per chunk) and the rows are scaled by seed[b] once at the end.
+    // BIT < 0: the mask bytes are 0/1 as stored (single plane written with BIT 0 + OVERWRITE); BIT >= 0 selects a plane.
+    // Same structure as fwd_loop: tiles owned is a template parameter, two register sets, no masks.
+    // ---------------------------------------------------------------------------------------
+    template <int NS, int NOWN, int BIT, bool TRICK>
+    __device__ __forceinline__ void bwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NTk, const lds_f32* seed,
+                                             const lds_f32* wvec) {
+        const float* wp = W + (((size_t)(NTW * wave) * NTk) << 8) + (lane << 2);
+        const lds_u8* mp = L.mask + c * MSTRIDE + 4 * g;
+        const lds_f32* wvp = wvec + 4 * g;
+        float sd[MT][NS];
+        if (!TRICK) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
+        }
+        f32x4 b0[NOWN], b1[NOWN];
+        auto loadB = [&](f32x4 (&dst)[NOWN], int ch) {
+#pragma unroll
+            for (int i = 0; i < NOWN; i++)
+                dst[i] = *reinterpret_cast<const f32x4*>(wp + (((size_t)i * NTk + ch) << 8));
+        };
+        auto mac = [&](const f32x4 (&bin)[NOWN], int ch) {
+            f32x4 wv[NS], b[NOWN];
+#pragma unroll
+            for (int j = 0; j < NS; j++) wv[j] = *reinterpret_cast<const lds_f32x4*>(wvp + j * 256 + 16 * ch);
+#pragma unroll
+            for (int i = 0; i < NOWN; i++) b[i] = TRICK ? bin[i] * wv[0] : bin[i];
+            f32x4 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                unsigned mw = *reinterpret_cast<const lds_u32*>(mp + 16 * mt * MSTRIDE + 16 * ch);
+                if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x01010101u;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const float f = (float)((mw >> (8 * s)) & 0xffu);        // v_cvt_f32_ubyte<s>: 0.0 or 1.0
+                    if (TRICK) {
+                        av[mt][s] = f;
+                    } else {
+                        float v = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < NS; j++) v += sd[mt][j] * wv[j][s];
+                        av[mt][s] = f * v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], b[i][s], acc[mt][i]);
+        };
+        loadB(b0, 0);
+        int ch = 0;
+        for (; ch + 2 <= NTk; ch += 2) {
+            loadB(b1, ch + 1);
+            mac(b0, ch);
+            if (ch + 2 < NTk) loadB(b0, ch + 2);      // wave-uniform
+            mac(b1, ch + 1);
+        }
+        if (ch < NTk) mac(b0, ch);
+        if (TRICK) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const f32x4 sv = *reinterpret_cast<const lds_f32x4*>(&seed[16 * mt + 4 * g]);
+#pragma unroll
+                for (int i = 0; i < NOWN; i++) acc[mt][i] = acc[mt][i] * sv;
+            }
+        }
+    }
+
+    // ACCUM: add onto the accumulators (a second branch that feeds the same input), else start from zero
+    template <int NS, int BIT = -1, bool ACCUM = false>
+    __device__ __forceinline__ void bwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int Nk /* row length = k-dim */,
+                                             int Kout /* rows of W used */, const lds_f32* seed /* LDS [MB][NS] */,
+                                             const lds_f32* wvec /* LDS [NS][256] */) {
+        const int NT = (Kout + 15) >> 4;
+        if (!ACCUM) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int nown = NT - NTW * wave;
+        const int NTk = (Nk + 15) >> 4;
+        constexpr bool TRICK = NS == 1 && !ACCUM;
+        if constexpr (NTW >= 2) {
+            if (nown >= 2) bwd_loop<NS, 2, BIT, TRICK>(acc, W, NTk, seed, wvec);
+            else if (nown == 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec);
+        } else {
+            if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec);
+        }
+    }
+
+    // epilogue of bwd_gemm: dh1 = (acc [+ extra(b, k)]) * (hbuf > 0); column-reduce into the W1 / b1 gradients of
+    // this wave's first-layer units and apply Adam (+ optional Polyak) right here.  xs = the layer's input rows
+    // (LDS [MB][SMAX]).  extra(b, k): further contributions to dL/dh1[b][k] (heads that hang off the first layer).
+    template <class EXTRA = NoExtra>
+    __device__ __forceinline__ void trunk_grad_adam(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
+                                                    float alpha, int oW1, int ob1, float* tap, float* tt, float tau,
+                                                    const lds_f32* xs, EXTRA extra = EXTRA{}) {
+        if (S <= 4) trunk_grad_adam_t<4>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);     // wave-uniform
+        else trunk_grad_adam_t<SMAX>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);
+    }
+    template <int SP, class EXTRA>
+    __device__ __forceinline__ void trunk_grad_adam_t(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
+                                                      float alpha, int oW1, int ob1, float* tap, float* tt, float tau,
+                                                      const lds_f32* xs, EXTRA extra) {
+        const int NT = (H1 + 15) >> 4;
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = NTW * wave + i;
+            if (t >= NT) continue;
+            const int k = 16 * t + c;
+            float gb = 0.0f;
+            float gw[SP];
+#pragma unroll
+            for (int s = 0; s < SP; s++) gw[s] = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int b = 16 * mt + 4 * g + r;
+                    const float hv = L.hbuf[b * LDH + (k < H1 ? k : 0)];
+                    float d;
+                    if constexpr (std::is_same<EXTRA, NoExtra>::value) {
+                        d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] : 0.0f;
+                    } else {
+                        d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] + extra(b, k < H1 ? k : 0) : 0.0f;
+                    }
+                    gb += d;
+                    const f32x4 x0 = *reinterpret_cast<const lds_f32x4*>(&xs[b * SMAX]);
+#pragma unroll
+                    for (int s = 0; s < 4; s++) gw[s] += x0[s] * d;
+                    if (SP > 4) {
+                        const f32x4 x1 = *reinterpret_cast<const lds_f32x4*>(&xs[b * SMAX + 4]);
+#pragma unroll
+                        for (int s = 0; s < 4; s++) gw[(SP > 4 ? 4 : 0) + s] += x1[s] * d;
+                    }
+                }
+            gb = col4_sum(gb);
+#pragma unroll
+            for (int s = 0; s < SP; s++) gw[s] = col4_sum(gw[s]);
+            // lanes g == s' handle row s' (spread the Adam work over the 4 lane groups)
+            if (k < H1) {
+                for (int s = g; s <= S; s += 4) {
+                    const bool is_bias = s == S;
+                    float gr = gb;
+#pragma unroll
+                    for (int q = 0; q < SP; q++)
+                        if (q == s && !is_bias) gr = gw[q];
+                    const int p = is_bias ? ob1 + k : oW1 + s * H1 + k;
+                    float mm = m[p], vv = v[p];
+                    const float nv = adam_step(th[p], gr, mm, vv, alpha);
+                    m[p] = mm; v[p] = vv; th[p] = nv;
+                    if (tap) tap[p] = gr;
+                    if (tt) { const float o = tt[p]; tt[p] = o + tau * (nv - o); }
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // weight-gradient GEMM + Adam (+Polyak) epilogue:
+    //   G[k'][n] = sum_b X[b][k'] * D[b][n],  X = [hbuf | E] (E = NE extra input columns, or none), D as above.
+    // TRANSPOSED tiles: acc[q][r] = G[k' = 16(m0+q) + c][n = 16t + 4g + r] (D^T on the A side, hbuf on the B
+    // side), so each lane owns 4 CONSECUTIVE n of one weight row = its 16 bytes of block (m0+q, t) of the
+    // tile-blocked arrays: the W / m / v / W' traffic of the Adam epilogue is one 1 KB-contiguous load and one
+    // store per array per tile.  k-dim = batch, lane group g takes b = 4*ks + {0,2,1,3}[g] (conflict-free reads).
+    //
+    // Work items = (N tile t, chunk of <= 4 M' tiles); the items of a matrix are dealt
+    // round-robin to the 8 waves (every output tile is independent: no cross-wave reduction), so all four SIMDs
+    // carry the same MFMA load.  While the k-loop of one item runs, the W / m / v / W' of the wave's NEXT item are
+    // already in flight into a second register set.
+    // ---------------------------------------------------------------------------------------
+    struct WgPre { f32x4 w[4], m[4], v[4], t[4]; };
+
+    template <int NS, int NE, int BIT = -1>
+    __device__ __forceinline__ void wgrad_adam(const lds_f32* seed /* LDS [MB][NS] */, const lds_f32* E /* LDS [MB][NE] or null */,
+                                               int N, float* Wp, float* mp, float* vp,
+                                               float alpha, float* tapp, float* Wt, float tau,
+                                               const lds_f32* wvec /* LDS [NS][256] */) {
+        const int NT = (N + 15) >> 4;
+        const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the hbuf units; extra rows below
+        const int nch = (NMT + 3) >> 2, cbase = NMT / nch, crem = NMT % nch;    // chunk sizes differ by at most one
+        const int nitems = NT * nch;
+        const int gperm = ((g & 1) << 1) | (g >> 1);     // 0,2,1,3
+        const int lane4 = (g * 16 + c) << 2;
+        constexpr unsigned MBITS = BIT < 0 ? 0xffu : (1u << (BIT < 0 ? 0 : BIT));
+
+        auto item_geom = [&](int idx, int& t, int& m0, int& nq) {
+            t = idx % NT;
+            const int ch = idx / NT;
+            nq = cbase + (ch < crem ? 1 : 0);
+            m0 = ch * cbase + (ch < crem ? ch : crem);
+        };
+        // Prefetch an item's W / m / v / W' NOW: their HBM latency hides under the previous item's k-loop
+        // (addresses clamped, stores predicated).
+        auto issue = [&](WgPre& P, int idx) {
+            int t, m0, nq;
+            item_geom(idx, t, m0, nq);
+            const bool n4ok = 16 * t + 4 * g < N;        // N % 4 == 0: all four columns valid or none
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int kp = 16 * (m0 + q) + c;
+                const size_t p = (q < nq && kp < H1 && n4ok) ? ((((size_t)(m0 + q) * NT + t) << 8) + lane4) : 0;
+                P.w[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
+                P.m[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
+                P.v[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
+                P.t[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
+            }
+        };
+        auto run = [&](const WgPre& P, int idx, auto mcc_tag) {
+            constexpr int MCC = decltype(mcc_tag)::value;
+            int t, m0, nq;
+            item_geom(idx, t, m0, nq);
+            const int n = 16 * t + c;
+            float wvn[NS];
+#pragma unroll
+            for (int j = 0; j < NS; j++) wvn[j] = n < N ? wvec[j * 256 + n] : 0.0f;
+            f32x4 acc[MCC];
+            int kq[MCC];
+#pragma unroll
+            for (int q = 0; q < MCC; q++) {
+                acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                kq[q] = (q < nq ? 16 * (m0 + q) : 0) + c;             // rows past the chunk alias tile 0 (never stored)
+            }
+            const lds_u8* mrow = L.mask + 16 * t + c;
+            sub_begin();
+#pragma unroll 4
+            for (int ks = 0; ks < MT * 4; ks++) {
+                const int b = 4 * ks + gperm;
+                // D[b][n] for this lane's (b, n = 16t + c)
+                float dv = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
+                const float df = (mrow[b * MSTRIDE] & MBITS) ? dv : 0.0f;
+                // hbuf fragments, unmasked: columns kp >= H1 (last tile only) only feed rows that are never stored
+                float hf[MCC];
+#pragma unroll
+                for (int q = 0; q < MCC; q++) hf[q] = L.hbuf[b * LDH + kq[q]];
+#pragma unroll
+                for (int q = 0; q < MCC; q++) acc[q] = mfma16(df, hf[q], acc[q]);
+            }
+            sub_stamp(22);
+            const bool n4ok = 16 * t + 4 * g < N;
+#pragma unroll
+            for (int q = 0; q < MCC; q++) {
+                const int kp = 16 * (m0 + q) + c;
+                f32x4 nw, nm = P.m[q], nv = P.v[q], nt;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float mm = nm[r], vv = nv[r];
+                    nw[r] = adam_step_fast(P.w[q][r], acc[q][r], mm, vv, alpha);
+                    nm[r] = mm; nv[r] = vv;
+                    nt[r] = P.t[q][r] + tau * (nw[r] - P.t[q][r]);
+                }
+                if (q < nq && kp < H1 && n4ok) {
+                    const size_t p = (((size_t)(m0 + q) * NT + t) << 8) + lane4;
+                    *reinterpret_cast<f32x4*>(&mp[p]) = nm;
+                    *reinterpret_cast<f32x4*>(&vp[p]) = nv;
+                    *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
+                    *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
+                    if (tapp) *reinterpret_cast<f32x4*>(&tapp[p]) = acc[q];
+                }
+            }
+            sub_stamp(23);
+        };
+        auto run_any = [&](const WgPre& P, int idx) {
+            const int ch = idx / NT;
+            if (cbase + (ch < crem ? 1 : 0) == 4) run(P, idx, std::integral_constant<int, 4>{});
+            else run(P, idx, std::integral_constant<int, 3>{});      // chunks of < 3 tiles alias tile 0 (never stored)
+        };
+
+        WgPre PA, PB;
+        int idx = wave;
+        sub_begin();
+        // Compiler-level memory barriers pin the prefetch loads and the epilogue stores where they are written:
+        // without them hipcc reorders the overlapped prefetch across the stores of the previous item / previous
+        // update (K updates in one launch then differ from K launches; tests/test_gpu_ddpg.py pins this).
+#define RLC_CBAR() asm volatile("" ::: "memory")
+        RLC_CBAR();
+        if (idx < nitems) issue(PA, idx);
+        sub_stamp(21);
+        while (idx < nitems) {
+            RLC_CBAR();
+            if (idx + kWaves < nitems) issue(PB, idx + kWaves);
+            RLC_CBAR();
+            run_any(PA, idx);
+            RLC_CBAR();
+            idx += kWaves;
+            if (idx >= nitems) break;
+            if (idx + kWaves < nitems) issue(PA, idx + kWaves);
+            RLC_CBAR();
+            run_any(PB, idx);
+            RLC_CBAR();
+            idx += kWaves;
+        }
+#undef RLC_CBAR
+        sub_begin();
+        // extra rows of a concat layer (rank-NE term): G[H1+j][n] = sum_b E[b][j] * D[b][n]; one N tile per
+        // wave at a time
+        if constexpr (NE > 0) {
+            for (int t = wave; t < NT; t += kWaves) {
+                const int n = 16 * t + c;
+                const bool nok = n < N;
+                float wvn[NS];
+#pragma unroll
+                for (int j = 0; j < NS; j++) wvn[j] = nok ? wvec[j * 256 + n] : 0.0f;
+                float ge[NE];
+#pragma unroll
+                for (int j = 0; j < NE; j++) ge[j] = 0.0f;
+                for (int bb = 0; bb < MB / 4; bb++) {
+                    const int b = 4 * bb + g;
+                    float dv = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
+                    const float dd = (L.mask[b * MSTRIDE + 16 * t + c] & MBITS) ? dv : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NE; j++) ge[j] += E[b * NE + j] * dd;
+                }
+#pragma unroll
+                for (int j = 0; j < NE; j++) {
+                    const float gr = col4_sum(ge[j]);
+                    if (g == j && nok) {
+                        const size_t p = rlc_blk_index(((H1 + 15) & ~15) + j, n, N);   // first extra block row + j
+                        float mm = mp[p], vv = vp[p];
+                        const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
+                        mp[p] = mm; vp[p] = vv; Wp[p] = nv;
+                        if (tapp) tapp[p] = gr;
+                        const float o = Wt[p];
+                        Wt[p] = o + tau * (nv - o);
+                    }
+                }
+            }
+        }
+        sub_stamp(24);
+    }
+
+    // Adam (+ Polyak) on one scalar parameter by the calling lane
+    __device__ __forceinline__ static void adam_scalar(float* th, float* m, float* v, float* tt, float* tap, int p,
+                                                       float gr, float alpha, float tau) {
+        float mm = m[p], vv = v[p];
+        const float nv = adam_step(th[p], gr, mm, vv, alpha);
+        m[p] = mm; v[p] = vv; th[p] = nv;
+        if (tap) tap[p] = gr;
+        if (tt) { const float o = tt[p]; tt[p] = o + tau * (nv - o); }
+    }
+};
+
+}  // namespace mfb

@@ -2,7 +2,8 @@
 // Blob = variable creation order (agents/network/naf_network.py:79-107):
 //   W1[S,L1] b1 | Wa2[L1,L2] ba2 | Wa3[L2,A] ba3 | Wv2[L1,L2] bv2 | Wv3[L2] bv3 |
 //   for c < A: Wd_c[L1] bd_c | for c < A-1: Wn_c[L1,A-1-c] bn_c[A-1-c]
-// Device layout pads every tensor to 64 floats; the ABI blob is compact.
+// Device layout pads every tensor to 64 floats; Wa2 / Wv2 are tile-blocked when the MFMA kernel is in use
+// (RlcNafDims::blocked); the ABI blob is compact row-major.
 #pragma once
 #include "rlc_common.h"
 
@@ -11,33 +12,31 @@
 
 struct RlcNafDims {
     int S, A, L1, L2, B, NN;    // NN = A(A-1)/2 below-diagonal entries
+    int blocked;                // 1: Wa2 / Wv2 segments use the tile-blocked layout of rlc_common.h (MFMA kernel)
     int W1, b1, Wa2, ba2, Wa3, ba3, Wv2, bv2, Wv3, bv3;
     int Wd[RLC_NAF_MAX_A], bd[RLC_NAF_MAX_A], Wn[RLC_NAF_MAX_A], bn[RLC_NAF_MAX_A];
     int P, Pdev, Ppad, nseg;
     int seg_len[RLC_NAF_MAX_SEG], seg_compact[RLC_NAF_MAX_SEG], seg_dev[RLC_NAF_MAX_SEG];
+    int seg_rows[RLC_NAF_MAX_SEG], seg_cols[RLC_NAF_MAX_SEG], seg_h[RLC_NAF_MAX_SEG];
+    char seg_big[RLC_NAF_MAX_SEG];
 };
 
-inline RlcNafDims rlc_naf_make_dims(int S, int A, int L1, int L2, int B) {
+inline RlcNafDims rlc_naf_make_dims(int S, int A, int L1, int L2, int B, int blocked = 0) {
     RlcNafDims d;
     d.S = S; d.A = A; d.L1 = L1; d.L2 = L2; d.B = B; d.NN = A * (A - 1) / 2;
-    int len[RLC_NAF_MAX_SEG];
+    d.blocked = blocked;
     int n = 0;
-    const int head[10] = {S * L1, L1, L1 * L2, L2, L2 * A, A, L1 * L2, L2, L2, 1};
-    for (int i = 0; i < 10; i++) len[n++] = head[i];
-    for (int c = 0; c < A; c++) { len[n++] = L1; len[n++] = 1; }
-    for (int c = 0; c < A - 1; c++) { len[n++] = L1 * (A - 1 - c); len[n++] = A - 1 - c; }
+    auto seg = [&](int r, int c, int big) { d.seg_rows[n] = r; d.seg_cols[n] = c; d.seg_h[n] = r; d.seg_big[n] = (char)big; n++; };
+    seg(S, L1, 0); seg(1, L1, 0); seg(L1, L2, 1); seg(1, L2, 0); seg(L2, A, 0); seg(1, A, 0);
+    seg(L1, L2, 1); seg(1, L2, 0); seg(L2, 1, 0); seg(1, 1, 0);
+    for (int c = 0; c < A; c++) { seg(L1, 1, 0); seg(1, 1, 0); }
+    for (int c = 0; c < A - 1; c++) { seg(L1, A - 1 - c, 0); seg(1, A - 1 - c, 0); }
     d.nseg = n;
-    int pc = 0, pd = 0;
-    for (int i = 0; i < n; i++) {
-        d.seg_len[i] = len[i]; d.seg_compact[i] = pc; d.seg_dev[i] = pd;
-        pc += len[i];
-        pd += (len[i] + 63) & ~63;
-    }
+    rlc_layout_segs(d);
     d.W1 = d.seg_dev[0]; d.b1 = d.seg_dev[1]; d.Wa2 = d.seg_dev[2]; d.ba2 = d.seg_dev[3]; d.Wa3 = d.seg_dev[4];
     d.ba3 = d.seg_dev[5]; d.Wv2 = d.seg_dev[6]; d.bv2 = d.seg_dev[7]; d.Wv3 = d.seg_dev[8]; d.bv3 = d.seg_dev[9];
     for (int c = 0; c < A; c++) { d.Wd[c] = d.seg_dev[10 + 2 * c]; d.bd[c] = d.seg_dev[11 + 2 * c]; }
     for (int c = 0; c < A - 1; c++) { d.Wn[c] = d.seg_dev[10 + 2 * A + 2 * c]; d.bn[c] = d.seg_dev[11 + 2 * A + 2 * c]; }
-    d.P = pc; d.Pdev = pd; d.Ppad = pd;
     return d;
 }
 

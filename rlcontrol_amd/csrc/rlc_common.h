@@ -130,6 +130,61 @@ inline void rlc_unpack_blob(const RlcDims& d, const float* padded, float* compac
     }
 }
 
+// Generic form of the two functions above for dims structs that carry a segment table (SAC, NAF): fields nseg,
+// blocked, seg_len / seg_compact / seg_dev / seg_rows / seg_cols, seg_big (1: a matrix that is tile-blocked when
+// d.blocked) and seg_h (rows fed by the hidden activation; rows seg_h.. are extra input rows -- a critic's action
+// rows -- which the blocked layout moves to a block row of their own, as RlcDims::arow0 does).
+template <class D>
+inline int rlc_seg_dev_row(const D& d, int i, int r) {
+    return (d.blocked && d.seg_big[i] && r >= d.seg_h[i]) ? ((d.seg_h[i] + 15) & ~15) + (r - d.seg_h[i]) : r;
+}
+template <class D>
+inline void rlc_pack_segs(const D& d, const float* compact, float* padded) {
+    for (int i = 0; i < d.nseg; i++) {
+        const float* src = compact + d.seg_compact[i];
+        float* dst = padded + d.seg_dev[i];
+        if (d.blocked && d.seg_big[i]) {
+            for (int r = 0; r < d.seg_rows[i]; r++)
+                for (int c = 0; c < d.seg_cols[i]; c++)
+                    dst[rlc_blk_index(rlc_seg_dev_row(d, i, r), c, d.seg_cols[i])] = src[(size_t)r * d.seg_cols[i] + c];
+        } else {
+            for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
+        }
+    }
+}
+template <class D>
+inline void rlc_unpack_segs(const D& d, const float* padded, float* compact) {
+    for (int i = 0; i < d.nseg; i++) {
+        float* dst = compact + d.seg_compact[i];
+        const float* src = padded + d.seg_dev[i];
+        if (d.blocked && d.seg_big[i]) {
+            for (int r = 0; r < d.seg_rows[i]; r++)
+                for (int c = 0; c < d.seg_cols[i]; c++)
+                    dst[(size_t)r * d.seg_cols[i] + c] = src[rlc_blk_index(rlc_seg_dev_row(d, i, r), c, d.seg_cols[i])];
+        } else {
+            for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
+        }
+    }
+}
+// lay the segments out: row-major segments padded to 64 floats; big ones to their block extent when blocked.
+// Ppad fits either layout, so a handle can switch kernels (and layouts) without reallocating.
+template <class D>
+inline void rlc_layout_segs(D& d) {
+    int pc = 0, pd = 0, pmax = 0;
+    for (int i = 0; i < d.nseg; i++) {
+        const int len = d.seg_rows[i] * d.seg_cols[i];
+        const int xr = d.seg_rows[i] - d.seg_h[i];
+        const int blk = d.seg_big[i] ? rlc_blk_floats(xr > 0 ? ((d.seg_h[i] + 15) & ~15) + xr : d.seg_rows[i], d.seg_cols[i]) : len;
+        d.seg_len[i] = len;
+        d.seg_compact[i] = pc;
+        d.seg_dev[i] = pd;
+        pc += len;
+        pd += (((d.seg_big[i] && d.blocked) ? blk : len) + 63) & ~63;
+        pmax += ((blk > len ? blk : len) + 63) & ~63;
+    }
+    d.P = pc; d.Pdev = pd; d.Ppad = pmax;
+}
+
 // Replay ring of ONE agent lives at agent*cap inside each SoA array.  Logical index 0 = oldest.
 struct RlcRingMeta {
     long long start;   // physical slot of the oldest transition
@@ -321,9 +376,11 @@ __device__ __forceinline__ float adam_alpha(float lr, float b1p, float b2p) {
 // sparse regime: one candidate per thread, duplicates (against lower-numbered threads) redrawn
 // until none remain -- equivalent in distribution to sequential sampling without replacement.
 // Every thread of the workgroup must call it; blockDim.x must be a multiple of RLC_MAX_BATCH (128).
+// (PI / PL: int / long long pointers into LDS, generic or address-space-3 typed)
+template <class PI, class PL>
 __device__ inline void rlc_sample_distinct(long long n, int k, unsigned long long key, unsigned long long call,
-                                           int* lds_pool /* >= 3*RLC_MAX_BATCH ints */, long long* out /* LDS, k */,
-                                           int* lds_dups /* 1 int */) {
+                                           PI lds_pool /* >= 3*RLC_MAX_BATCH ints */, PL out /* LDS, k */,
+                                           PI lds_dups /* 1 int */) {
     const int tid = threadIdx.x;
     if (3LL * k >= n) {
         for (int i = tid; i < (int)n; i += blockDim.x) lds_pool[i] = i;
@@ -346,7 +403,7 @@ __device__ inline void rlc_sample_distinct(long long n, int k, unsigned long lon
     long long mine = -1;
     unsigned int round = 0;
     bool need = tid < k;
-    int* flag = lds_pool;                     // k ints (the dense regime's pool is free here)
+    PI flag = lds_pool;                       // k ints (the dense regime's pool is free here)
     const int t = tid & (RLC_MAX_BATCH - 1);
     const int part = tid / RLC_MAX_BATCH, nparts = (blockDim.x + RLC_MAX_BATCH - 1) / RLC_MAX_BATCH;
     const int span = (RLC_MAX_BATCH + nparts - 1) / nparts;

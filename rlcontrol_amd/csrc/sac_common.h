@@ -2,7 +2,8 @@
 // Blob = variable creation order under 'main' (agents/network/sac_network.py:152-172):
 //   pi: W1[S,L1a] b1 W2[L1a,L2a] b2 Wm[L2a,A] bm Ws[L2a,A] bs | qf: W1[S,L1c] b1 W2[L1c+A,L2c] b2 W3[L2c] b3 |
 //   vf: W1[S,L1c] b1 W2[L1c,L2c] b2 W3[L2c] b3
-// Device layout pads every tensor to 64 floats (same scheme as RlcDims); the ABI blob is compact.
+// Device layout pads every tensor to 64 floats (same scheme as RlcDims); the three L1 x L2 matrices are tile-blocked
+// when the MFMA kernel is in use (RlcSacDims::blocked); the ABI blob is compact row-major.
 #pragma once
 #include "rlc_common.h"
 
@@ -10,29 +11,34 @@
 
 struct RlcSacDims {
     int S, A, L1A, L2A, L1C, L2C, B;
+    int blocked;     // 1: pW2 / qW2 / vW2 segments use the tile-blocked layout of rlc_common.h (MFMA kernel)
+    int arow0;       // device row of qW2's first action row: L1C (row-major) or the next multiple of 16 (blocked)
     int pW1, pb1, pW2, pb2, pWm, pbm, pWs, pbs, qW1, qb1, qW2, qb2, qW3, qb3, vW1, vb1, vW2, vb2, vW3, vb3;
     int Ppi_dev;     // device offset where the qf block starts (pi optimizer owns [0, Ppi_dev))
-    int P, Pdev, Ppad;
+    int P, Pdev, Ppad, nseg;
     int seg_len[RLC_SAC_NSEG], seg_compact[RLC_SAC_NSEG], seg_dev[RLC_SAC_NSEG];
+    int seg_rows[RLC_SAC_NSEG], seg_cols[RLC_SAC_NSEG], seg_h[RLC_SAC_NSEG];
+    char seg_big[RLC_SAC_NSEG];
 };
 
-inline RlcSacDims rlc_sac_make_dims(int S, int A, int L1A, int L2A, int L1C, int L2C, int B) {
+inline RlcSacDims rlc_sac_make_dims(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, int blocked = 0) {
     RlcSacDims d;
     d.S = S; d.A = A; d.L1A = L1A; d.L2A = L2A; d.L1C = L1C; d.L2C = L2C; d.B = B;
-    const int len[RLC_SAC_NSEG] = {S * L1A, L1A, L1A * L2A, L2A, L2A * A, A, L2A * A, A,
-                                   S * L1C, L1C, (L1C + A) * L2C, L2C, L2C, 1,
-                                   S * L1C, L1C, L1C * L2C, L2C, L2C, 1};
-    int pc = 0, pd = 0;
+    d.blocked = blocked;
+    d.arow0 = blocked ? ((L1C + 15) & ~15) : L1C;
+    d.nseg = RLC_SAC_NSEG;
+    const int rows[RLC_SAC_NSEG] = {S, 1, L1A, 1, L2A, 1, L2A, 1, S, 1, L1C + A, 1, L2C, 1, S, 1, L1C, 1, L2C, 1};
+    const int cols[RLC_SAC_NSEG] = {L1A, L1A, L2A, L2A, A, A, A, A, L1C, L1C, L2C, L2C, 1, 1, L1C, L1C, L2C, L2C, 1, 1};
     for (int i = 0; i < RLC_SAC_NSEG; i++) {
-        d.seg_len[i] = len[i]; d.seg_compact[i] = pc; d.seg_dev[i] = pd;
-        pc += len[i];
-        pd += (len[i] + 63) & ~63;
+        d.seg_rows[i] = rows[i]; d.seg_cols[i] = cols[i];
+        d.seg_big[i] = (i == 2 || i == 10 || i == 16) ? 1 : 0;
+        d.seg_h[i] = i == 10 ? L1C : rows[i];
     }
+    rlc_layout_segs(d);
     int* o[RLC_SAC_NSEG] = {&d.pW1, &d.pb1, &d.pW2, &d.pb2, &d.pWm, &d.pbm, &d.pWs, &d.pbs, &d.qW1, &d.qb1,
                             &d.qW2, &d.qb2, &d.qW3, &d.qb3, &d.vW1, &d.vb1, &d.vW2, &d.vb2, &d.vW3, &d.vb3};
     for (int i = 0; i < RLC_SAC_NSEG; i++) *o[i] = d.seg_dev[i];
     d.Ppi_dev = d.qW1;
-    d.P = pc; d.Pdev = pd; d.Ppad = pd;
     return d;
 }
 
