@@ -181,6 +181,11 @@ int rlc_sac_update_batch(rlc_sac* h, int32_t agent, int32_t batch, const double*
  * fetches of train_ops (sac_network.py:135-136); 5 gradient blob (n = P, needs rlc_sac_enable_grad_taps) */
 int rlc_sac_last_tap(rlc_sac* h, int32_t agent, int32_t which, float* dst, int64_t n);
 int rlc_sac_enable_grad_taps(rlc_sac* h, int32_t on);
+/* kernel selection (no reference counterpart: one tf.Graph there): 0 auto, 1 generic fp32 VALU kernel (any shape),
+ * 2 MFMA kernel (S <= 8, A <= 2, layer widths multiples of 4 in [16,256], LDS permitting).  Switching re-packs the
+ * weights between the row-major and the tile-blocked device layout; results differ only in summation order. */
+int rlc_sac_set_kernel(rlc_sac* h, int32_t variant);
+int rlc_sac_get_kernel(const rlc_sac* h, int32_t* variant_in_use);
 
 
 /* ===================================== NAF =========================================================
@@ -219,6 +224,9 @@ int rlc_naf_update_batch(rlc_naf* h, int32_t agent, int32_t batch, const double*
 /* taps of the last update: 0 Q(s,a), 1 TD target y, 2 V(s) (n = batch); 3 gradient blob (n = P) */
 int rlc_naf_last_tap(rlc_naf* h, int32_t agent, int32_t which, float* dst, int64_t n);
 int rlc_naf_enable_grad_taps(rlc_naf* h, int32_t on);
+/* kernel selection, as rlc_sac_set_kernel: 0 auto, 1 generic, 2 MFMA (S <= 8, A <= 2, widths multiples of 4 in [16,256]) */
+int rlc_naf_set_kernel(rlc_naf* h, int32_t variant);
+int rlc_naf_get_kernel(const rlc_naf* h, int32_t* variant_in_use);
 
 /* ---------------------------------------------------------------------------------------------------
  * On-device experiment loop: Experiment.run of the reference

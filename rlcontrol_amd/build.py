@@ -14,11 +14,13 @@ CSRC = os.path.join(_HERE, "csrc")
 STAMPS = os.environ.get("RLC_STAMPS", "0") == "1"
 OBJ = os.path.join(CSRC, ("_obj_stamps" if STAMPS else "_obj") + ("_fast" if os.environ.get("RLC_FAST_BUILD", "0") == "1" else ""))
 OUT = os.path.join(_HERE, "librlcontrol_hip_stamps.so" if STAMPS else "librlcontrol_hip.so")
-PLAIN = ("rlc_api.hip", "rlc_api_sac.hip", "rlc_api_naf.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip", "sac_generic.hip", "naf_generic.hip", "rollout_kernels.hip", "rlc_api_rollout.hip")
+PLAIN = ("rlc_api.hip", "rlc_api_sac.hip", "rlc_api_naf.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip", "sac_generic.hip", "sac_mfma.hip", "naf_generic.hip", "naf_mfma.hip", "rollout_kernels.hip", "rlc_api_rollout.hip")
 MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]
 FAST = os.environ.get("RLC_FAST_BUILD", "0") == "1"     # developer loop: only the headline shape
+SAC_VARIANTS = [(mt, ntw, ad) for ad in (1, 2) for ntw in (1, 2) for mt in (2, 4, 7, 8)]
 if FAST:
     MFMA_VARIANTS = [(7, 1)]
+    SAC_VARIANTS = [(7, 1, 1)]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-Wno-unused-result"] + (["-DRLC_STAMPS"] if STAMPS else [])
 if os.environ.get("RLC_FAST_BUILD", "0") == "1":
     CFLAGS.append("-DRLC_ONLY_7_1")
@@ -39,6 +41,9 @@ def _units():
     for mt, ad in MFMA_VARIANTS:
         units.append((os.path.join(CSRC, "ddpg_mfma_inst.hip"), os.path.join(OBJ, "ddpg_mfma_%d_%d.o" % (mt, ad)),
                       ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
+    for mt, ntw, ad in SAC_VARIANTS:
+        units.append((os.path.join(CSRC, "sac_mfma_inst.hip"), os.path.join(OBJ, "sac_mfma_%d_%d_%d.o" % (mt, ntw, ad)),
+                      ["-DRLC_MT=%d" % mt, "-DRLC_NTW=%d" % ntw, "-DRLC_AD=%d" % ad]))
     return units
 
 

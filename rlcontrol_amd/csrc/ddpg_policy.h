@@ -13,30 +13,6 @@ __host__ __device__ inline size_t ddpg_policy_lds_floats(const RlcDims& d) {
     return (size_t)((d.S + 3) & ~3) + ((d.H1 + 3) & ~3) + ((d.HA + 3) & ~3) + ((d.A + 3) & ~3);
 }
 
-// column n of a [rows, ncols] weight matrix in either device layout (row-major or tile-blocked, rlc_common.h):
-// at(k0) points at row k0; rows k0+i of the same 16-row block follow at i*step floats.
-struct RlcWCol {
-    const float* p;
-    int step, rowblk, blocked;
-    __device__ __forceinline__ const float* at(int k0) const {
-        return blocked ? p + (size_t)(k0 >> 4) * rowblk + ((k0 & 15) << 2) : p + (size_t)k0 * step;
-    }
-};
-__device__ __forceinline__ RlcWCol rlc_wcol(const float* W, int blocked, int n, int ncols) {
-    RlcWCol w;
-    w.blocked = blocked;
-    if (blocked) {
-        w.p = W + ((n >> 4) << 8) + (((n & 15) >> 2) << 6) + (n & 3);
-        w.step = 4;
-        w.rowblk = ((ncols + 15) >> 4) << 8;
-    } else {
-        w.p = W + n;
-        w.step = ncols;
-        w.rowblk = 0;
-    }
-    return w;
-}
-
 struct DdpgPolicyLds {
     float *x, *h1, *h2, *act;
 };

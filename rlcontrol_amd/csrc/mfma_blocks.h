@@ -90,10 +90,16 @@ struct BlkLds {
 
 struct NoExtra {};
 
-// MT: M tiles (batch rows / 16); NTW: N tiles per wave (1: widths <= 128, 2: widths <= 256); MSTRIDE: mask row bytes
-template <int MT, int NTW, int MSTRIDE>
+// MT: M tiles (batch rows / 16); NTW: N tiles per wave (1: widths <= 128, 2: widths <= 256); MSTRIDE: mask row bytes;
+// LERP: target update written (1-tau)*t + tau*w (sac_network.py:72-73) instead of t + tau*(w - t)
+// (hydra_ddpg_network.py:29, naf_network.py:62-63)
+template <int MT, int NTW, int MSTRIDE, bool LERP = false>
 struct Blk {
     static constexpr int MB = MT * 16;
+
+    __device__ __forceinline__ static float polyak(float t, float w, float tau) {
+        return LERP ? (1.0f - tau) * t + tau * w : t + tau * (w - t);
+    }
 
     // per-thread geometry
     int tid, lane, wave, c, g;
@@ -296,6 +302,60 @@ struct Blk {
         return s;
     }
 
+    // Heads of a concat layer evaluated at a second set of extra inputs WITHOUT touching the accumulators:
+    //   v = relu(acc + bias[n] + sum_j E[b][j] Wx[xrow0+j][n]);  part[wave][b][0]   = sum_n v * w3[n]   (the layer's scalar head)
+    //                                                            part[wave][b][1+j] = sum_n step(v) * w3[n] * Wx[xrow0+j][n]
+    // (d head / d E[b][j]): Q(s, pi) and dQ/da of a critic whose hidden contraction is shared with Q(s, a).
+    template <int NE>
+    __device__ __forceinline__ void concat_head_dots(const f32x4 (&acc)[MT][NTW], const float* bias, int N, const lds_f32* E,
+                                                     const float* Wx, int xrow0, const float* w3, lds_f32* part) {
+        const int NT = (N + 15) >> 4;
+        float bs[NTW], w3n[NTW], wx[NTW][NE];
+        bool okk[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = NTW * wave + i;
+            const int n = 16 * t + c;
+            const bool ok = t < NT && n < N;
+            okk[i] = ok;
+            bs[i] = ok ? bias[n] : 0.0f;
+            w3n[i] = ok ? w3[n] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < NE; j++) wx[i][j] = ok ? Wx[rlc_blk_index(xrow0 + j, n, N)] : 0.0f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int b = 16 * mt + 4 * g + r;
+                float e[NE];
+#pragma unroll
+                for (int j = 0; j < NE; j++) e[j] = E[b * NE + j];
+                float p0 = 0.0f, pj[NE];
+#pragma unroll
+                for (int j = 0; j < NE; j++) pj[j] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NTW; i++) {
+                    float v = acc[mt][i][r] + bs[i];
+#pragma unroll
+                    for (int j = 0; j < NE; j++) v += e[j] * wx[i][j];
+                    v = okk[i] ? fmaxf(v, 0.0f) : 0.0f;
+                    p0 += v * w3n[i];
+#pragma unroll
+                    for (int j = 0; j < NE; j++) pj[j] += v > 0.0f ? w3n[i] * wx[i][j] : 0.0f;
+                }
+                p0 = row16_sum(p0);
+#pragma unroll
+                for (int j = 0; j < NE; j++) pj[j] = row16_sum(pj[j]);
+                if (c == 0) {
+                    lds_f32* dst = part + ((size_t)wave * MB + b) * (1 + NE);
+                    dst[0] = p0;
+#pragma unroll
+                    for (int j = 0; j < NE; j++) dst[1 + j] = pj[j];
+                }
+            }
+    }
+
     // relu masks of the accumulators -> bit plane BIT of one byte per (row, unit).  OVERWRITE: the byte becomes
     // the mask of this plane alone (other planes cleared); otherwise the plane is OR-ed in (the same thread owns
     // the same byte for every plane: no race).
@@ -484,7 +544,7 @@ struct Blk {
                     const float nv = adam_step(th[p], gr, mm, vv, alpha);
                     m[p] = mm; v[p] = vv; th[p] = nv;
                     if (tap) tap[p] = gr;
-                    if (tt) { const float o = tt[p]; tt[p] = o + tau * (nv - o); }
+                    if (tt) tt[p] = polyak(tt[p], nv, tau);
                 }
             }
         }
@@ -583,7 +643,7 @@ struct Blk {
                     float mm = nm[r], vv = nv[r];
                     nw[r] = adam_step_fast(P.w[q][r], acc[q][r], mm, vv, alpha);
                     nm[r] = mm; nv[r] = vv;
-                    nt[r] = P.t[q][r] + tau * (nw[r] - P.t[q][r]);
+                    nt[r] = polyak(P.t[q][r], nw[r], tau);
                 }
                 if (q < nq && kp < H1 && n4ok) {
                     const size_t p = (((size_t)(m0 + q) * NT + t) << 8) + lane4;
@@ -658,8 +718,7 @@ struct Blk {
                         const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
                         mp[p] = mm; vp[p] = vv; Wp[p] = nv;
                         if (tapp) tapp[p] = gr;
-                        const float o = Wt[p];
-                        Wt[p] = o + tau * (nv - o);
+                        Wt[p] = polyak(Wt[p], nv, tau);
                     }
                 }
             }
@@ -674,7 +733,7 @@ struct Blk {
         const float nv = adam_step(th[p], gr, mm, vv, alpha);
         m[p] = mm; v[p] = vv; th[p] = nv;
         if (tap) tap[p] = gr;
-        if (tt) { const float o = tt[p]; tt[p] = o + tau * (nv - o); }
+        if (tt) tt[p] = polyak(tt[p], nv, tau);
     }
 };
 

@@ -60,6 +60,10 @@ struct RlcNafRollout;   // naf_rollout_device.h: {RlcNafDev, RlcEnvDev, noise} i
 // rollout (device pointer, may be null): every iteration first takes one environment step of the on-device loop
 int rlc_launch_naf_update(const RlcNafDev& dv, int first_agent, int n_agents, int n_updates, int source,
                           const long long* idx_dev, int grad_taps, hipStream_t st, const RlcNafRollout* rollout = nullptr);
+// MFMA-tiled fused update (dims must satisfy rlc_naf_mfma_supported; tile-blocked layout)
+bool rlc_naf_mfma_supported(const RlcNafDims& d);
+int rlc_launch_naf_update_mfma(const RlcNafDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                               const long long* idx_dev, int grad_taps, hipStream_t st, const RlcNafRollout* rollout = nullptr);
 int rlc_launch_naf_eval(const RlcNafDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);
 // greedy action mu [n][A] and the L columns [n][A(A+1)/2] (column c = diag_c, then its below-diagonal entries)
 int rlc_launch_naf_act(const RlcNafDev& dv, int first_agent, int n, const float* states_dev, float* mu_dev,

@@ -41,7 +41,8 @@ __device__ inline void naf_policy_forward(const RlcNafDims& d, const float* th, 
     __syncthreads();
     blk_dense(L.x, S, S, nullptr, 0, th + d.W1, th + d.b1, L1, L.h1, L1, 1, 1);
     __syncthreads();
-    blk_dense(L.h1, L1, L1, nullptr, 0, th + d.Wa2, th + d.ba2, L2, L.ha, L2, 1, 1);
+    if (d.blocked) rlc_hidden_forward_row(th + d.Wa2, 1, th + d.ba2, L.h1, L1, L2, L.ha);
+    else blk_dense(L.h1, L1, L1, nullptr, 0, th + d.Wa2, th + d.ba2, L2, L.ha, L2, 1, 1);
     for (int c = 0; c < A; c++) blk_dense(L.h1, L1, L1, nullptr, 0, th + d.Wd[c], th + d.bd[c], 1, L.dpre + c, A, 1, 0);
     {
         int off = 0;

@@ -1,6 +1,8 @@
 // rlc_api_naf.hip -- C ABI of the NAF population (declared in include/rlcontrol_hip.h).
 #include <string.h>
 
+#include <algorithm>
+
 #include "rlc_handle.h"
 
 #define RLC_NEED_NAF(h) RLC_REQUIRE((h) && (h)->algo == RLC_ALGO_NAF, "handle is not a NAF population")
@@ -22,11 +24,44 @@ int naf_fetch_blob(rlc_handle* h, const float* dev_src, float* dst) {
     std::vector<float> padded(d.Ppad);
     RLC_HIP(hipMemcpyAsync(padded.data(), dev_src, sizeof(float) * d.Ppad, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
-    for (int i = 0; i < d.nseg; i++) memcpy(dst + d.seg_compact[i], &padded[d.seg_dev[i]], sizeof(float) * d.seg_len[i]);
+    rlc_unpack_segs(d, padded.data(), dst);
+    return 0;
+}
+
+// Re-pack the four per-agent blobs when the kernel variant (and with it the weight layout) changes.
+int naf_relayout(rlc_handle* h, int blocked) {
+    if (h->naf.d.blocked == blocked) return 0;
+    if (rlc_h_use_device(h)) return 1;
+    const RlcNafDims od = h->naf.d;
+    const RlcNafDims nd = rlc_naf_make_dims(od.S, od.A, od.L1, od.L2, od.B, blocked);
+    const size_t NA = h->naf.n_agents, PP = od.Ppad;
+    std::vector<float> dev(NA * PP), compact(od.P), out(NA * PP);
+    for (int which = 0; which < 4; which++) {
+        float* base = naf_blob(h, which);
+        RLC_HIP(hipMemcpyAsync(dev.data(), base, sizeof(float) * NA * PP, hipMemcpyDeviceToHost, h->st));
+        RLC_HIP(hipStreamSynchronize(h->st));
+        std::fill(out.begin(), out.end(), 0.0f);
+        for (size_t a = 0; a < NA; a++) {
+            rlc_unpack_segs(od, &dev[a * PP], compact.data());
+            rlc_pack_segs(nd, compact.data(), &out[a * PP]);
+        }
+        RLC_HIP(hipMemcpyAsync(base, out.data(), sizeof(float) * NA * PP, hipMemcpyHostToDevice, h->st));
+        RLC_HIP(hipStreamSynchronize(h->st));
+    }
+    h->naf.d = nd;
     return 0;
 }
 
 }  // namespace
+
+int rlc_h_naf_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
+                            const RlcNafRollout* rollout) {
+    if (rlc_h_naf_variant(h) == 2) {
+        RLC_REQUIRE(rlc_naf_mfma_supported(h->naf.d), "MFMA NAF kernel does not support these dimensions");
+        return rlc_launch_naf_update_mfma(h->naf, first, n, n_updates, source, idx_dev, h->grad_taps, h->st, rollout);
+    }
+    return rlc_launch_naf_update(h->naf, first, n, n_updates, source, idx_dev, h->grad_taps, h->st, rollout);
+}
 
 extern "C" {
 
@@ -41,6 +76,9 @@ int rlc_naf_create(const rlc_naf_config* cfg, rlc_handle** out) {
     if (rc) { rlc_h_destroy(h); return rc; }
     RlcNafDev& dv = h->naf;
     dv.d = rlc_naf_make_dims(cfg->state_dim, cfg->action_dim, cfg->l1_dim, cfg->l2_dim, cfg->batch_size);
+    // the tile-blocked weight layout goes with the MFMA kernel (the default whenever it supports the shape)
+    if (rlc_naf_mfma_supported(dv.d))
+        dv.d = rlc_naf_make_dims(cfg->state_dim, cfg->action_dim, cfg->l1_dim, cfg->l2_dim, cfg->batch_size, 1);
     dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
     dv.clip_state = cfg->clip_state;
@@ -94,7 +132,7 @@ int rlc_naf_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* s
     const RlcNafDims& d = h->naf.d;
     RLC_REQUIRE(n == d.P, "blob length %lld != parameter count %d", (long long)n, d.P);
     std::vector<float> padded(d.Ppad, 0.0f);
-    for (int i = 0; i < d.nseg; i++) memcpy(&padded[d.seg_dev[i]], src + d.seg_compact[i], sizeof(float) * d.seg_len[i]);
+    rlc_pack_segs(d, src, padded.data());
     RLC_HIP(hipMemcpyAsync(base + (size_t)agent * d.Ppad, padded.data(), sizeof(float) * d.Ppad, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
@@ -171,7 +209,7 @@ int rlc_naf_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices
         RLC_HIP(hipMemcpyAsync(h->idx_dev, host_indices, sizeof(long long) * count, hipMemcpyHostToDevice, h->st));
         source = RLC_SRC_REPLAY_HOST_INDICES;
     }
-    return rlc_launch_naf_update(h->naf, 0, NA, n_updates, source, h->idx_dev, h->grad_taps, h->st);
+    return rlc_h_naf_launch_update(h, 0, NA, n_updates, source, h->idx_dev, nullptr);
 }
 
 int rlc_naf_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const double* states, const double* actions,
@@ -195,7 +233,24 @@ int rlc_naf_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const doub
     RLC_HIP(hipMemcpyAsync(h->rep.gs + slot * S, hf, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipMemcpyAsync(h->rep.gs2 + slot * S, hf + B * S, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipMemcpyAsync(h->rep.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
-    return rlc_launch_naf_update(h->naf, agent, 1, 1, RLC_SRC_STAGING, nullptr, h->grad_taps, h->st);
+    return rlc_h_naf_launch_update(h, agent, 1, 1, RLC_SRC_STAGING, nullptr, nullptr);
+}
+
+int rlc_naf_set_kernel(rlc_handle* h, int32_t variant) {
+    RLC_REQUIRE(h, "null handle");
+    RLC_NEED_NAF(h);
+    RLC_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (auto), 1 (generic) or 2 (mfma)");
+    RLC_REQUIRE(variant != 2 || rlc_naf_mfma_supported(h->naf.d), "MFMA NAF kernel does not support these dimensions");
+    RLC_REQUIRE(!h->has_env, "the kernel variant cannot change once a rollout is attached to the handle");
+    h->variant = variant;
+    return naf_relayout(h, rlc_h_naf_variant(h) == 2 ? 1 : 0);
+}
+
+int rlc_naf_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {
+    RLC_REQUIRE(h && variant_in_use, "null argument");
+    RLC_NEED_NAF(h);
+    *variant_in_use = rlc_h_naf_variant(h);
+    return 0;
 }
 
 int rlc_naf_enable_grad_taps(rlc_handle* h, int32_t on) {

@@ -134,14 +134,15 @@ static int rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps)
         long long n = h->ro_eval_interval - h->ro_steps % h->ro_eval_interval;      // steps to the next evaluation
         if (n > todo) n = todo;
         if (n > kMaxPerLaunch) n = kMaxPerLaunch;
-        if (sac) {
-            if (rlc_launch_sac_update(h->sac, 0, h->sac.n_agents, (int)n, RLC_SRC_REPLAY_DEVICE_SAMPLER, nullptr, nullptr, 0,
-                                      h->st, h->sac_rollout_dev))
-                return 1;
-        } else if (naf) {
-            if (rlc_launch_naf_update(h->naf, 0, h->naf.n_agents, (int)n, RLC_SRC_REPLAY_DEVICE_SAMPLER, nullptr, 0, h->st,
-                                      h->naf_rollout_dev))
-                return 1;
+        if (sac || naf) {
+            const int taps = h->grad_taps;
+            h->grad_taps = 0;                      // the fused loop writes no gradient taps
+            const int rc = sac ? rlc_h_sac_launch_update(h, 0, h->sac.n_agents, (int)n, RLC_SRC_REPLAY_DEVICE_SAMPLER, nullptr,
+                                                         nullptr, h->sac_rollout_dev)
+                               : rlc_h_naf_launch_update(h, 0, h->naf.n_agents, (int)n, RLC_SRC_REPLAY_DEVICE_SAMPLER, nullptr,
+                                                         h->naf_rollout_dev);
+            h->grad_taps = taps;
+            if (rc) return 1;
         } else if (launch_steps(h, (int)n, h->ro_pending_q8)) {
             return 1;
         }

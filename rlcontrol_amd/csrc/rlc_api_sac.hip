@@ -1,6 +1,8 @@
 // rlc_api_sac.hip -- C ABI of the SoftActorCritic population (declared in include/rlcontrol_hip.h).
 #include <string.h>
 
+#include <algorithm>
+
 #include "rlc_handle.h"
 
 #define RLC_NEED_SAC(h) RLC_REQUIRE((h) && (h)->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population")
@@ -22,8 +24,31 @@ int sac_fetch_blob(rlc_handle* h, const float* dev_src, float* dst) {
     std::vector<float> padded(d.Ppad);
     RLC_HIP(hipMemcpyAsync(padded.data(), dev_src, sizeof(float) * d.Ppad, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
-    for (int i = 0; i < RLC_SAC_NSEG; i++)
-        memcpy(dst + d.seg_compact[i], &padded[d.seg_dev[i]], sizeof(float) * d.seg_len[i]);
+    rlc_unpack_segs(d, padded.data(), dst);
+    return 0;
+}
+
+// Re-pack the four per-agent blobs when the kernel variant (and with it the weight layout) changes.
+int sac_relayout(rlc_handle* h, int blocked) {
+    if (h->sac.d.blocked == blocked) return 0;
+    if (rlc_h_use_device(h)) return 1;
+    const RlcSacDims od = h->sac.d;
+    const RlcSacDims nd = rlc_sac_make_dims(od.S, od.A, od.L1A, od.L2A, od.L1C, od.L2C, od.B, blocked);
+    const size_t NA = h->sac.n_agents, PP = od.Ppad;
+    std::vector<float> dev(NA * PP), compact(od.P), out(NA * PP);
+    for (int which = 0; which < 4; which++) {
+        float* base = sac_blob(h, which);
+        RLC_HIP(hipMemcpyAsync(dev.data(), base, sizeof(float) * NA * PP, hipMemcpyDeviceToHost, h->st));
+        RLC_HIP(hipStreamSynchronize(h->st));
+        std::fill(out.begin(), out.end(), 0.0f);
+        for (size_t a = 0; a < NA; a++) {
+            rlc_unpack_segs(od, &dev[a * PP], compact.data());
+            rlc_pack_segs(nd, compact.data(), &out[a * PP]);
+        }
+        RLC_HIP(hipMemcpyAsync(base, out.data(), sizeof(float) * NA * PP, hipMemcpyHostToDevice, h->st));
+        RLC_HIP(hipStreamSynchronize(h->st));
+    }
+    h->sac.d = nd;
     return 0;
 }
 
@@ -42,6 +67,15 @@ int upload_eps(rlc_handle* h, const float* eps, size_t count, const float** out_
 
 }  // namespace
 
+int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
+                            const float* eps_dev, const RlcSacRollout* rollout) {
+    if (rlc_h_sac_variant(h) == 2) {
+        RLC_REQUIRE(rlc_sac_mfma_supported(h->sac.d), "MFMA SAC kernel does not support these dimensions");
+        return rlc_launch_sac_update_mfma(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st, rollout);
+    }
+    return rlc_launch_sac_update(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st, rollout);
+}
+
 extern "C" {
 
 int rlc_sac_create(const rlc_sac_config* cfg, rlc_handle** out) {
@@ -56,6 +90,10 @@ int rlc_sac_create(const rlc_sac_config* cfg, rlc_handle** out) {
     RlcSacDev& dv = h->sac;
     dv.d = rlc_sac_make_dims(cfg->state_dim, cfg->action_dim, cfg->actor_l1_dim, cfg->actor_l2_dim,
                              cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size);
+    // the tile-blocked weight layout goes with the MFMA kernel (the default whenever it supports the shape)
+    if (rlc_sac_mfma_supported(dv.d))
+        dv.d = rlc_sac_make_dims(cfg->state_dim, cfg->action_dim, cfg->actor_l1_dim, cfg->actor_l2_dim,
+                                 cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size, 1);
     dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
     dv.clip_state = cfg->clip_state;
@@ -112,8 +150,7 @@ int rlc_sac_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* s
     const RlcSacDims& d = h->sac.d;
     RLC_REQUIRE(n == d.P, "blob length %lld != parameter count %d", (long long)n, d.P);
     std::vector<float> padded(d.Ppad, 0.0f);
-    for (int i = 0; i < RLC_SAC_NSEG; i++)
-        memcpy(&padded[d.seg_dev[i]], src + d.seg_compact[i], sizeof(float) * d.seg_len[i]);
+    rlc_pack_segs(d, src, padded.data());
     RLC_HIP(hipMemcpyAsync(base + (size_t)agent * d.Ppad, padded.data(), sizeof(float) * d.Ppad, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
@@ -204,7 +241,7 @@ int rlc_sac_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices
         source = RLC_SRC_REPLAY_HOST_INDICES;
     }
     if (upload_eps(h, eps, count * A, &eps_dev, idx_count)) return 1;
-    return rlc_launch_sac_update(h->sac, 0, NA, n_updates, source, h->idx_dev, eps_dev, h->grad_taps, h->st);
+    return rlc_h_sac_launch_update(h, 0, NA, n_updates, source, h->idx_dev, eps_dev, nullptr);
 }
 
 int rlc_sac_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const double* states, const double* actions,
@@ -230,7 +267,24 @@ int rlc_sac_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const doub
     RLC_HIP(hipMemcpyAsync(h->rep.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
     const float* eps_dev = nullptr;
     if (upload_eps(h, eps, B * A, &eps_dev, 0)) return 1;
-    return rlc_launch_sac_update(h->sac, agent, 1, 1, RLC_SRC_STAGING, nullptr, eps_dev, h->grad_taps, h->st);
+    return rlc_h_sac_launch_update(h, agent, 1, 1, RLC_SRC_STAGING, nullptr, eps_dev, nullptr);
+}
+
+int rlc_sac_set_kernel(rlc_handle* h, int32_t variant) {
+    RLC_REQUIRE(h, "null handle");
+    RLC_NEED_SAC(h);
+    RLC_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (auto), 1 (generic) or 2 (mfma)");
+    RLC_REQUIRE(variant != 2 || rlc_sac_mfma_supported(h->sac.d), "MFMA SAC kernel does not support these dimensions");
+    RLC_REQUIRE(!h->has_env, "the kernel variant cannot change once a rollout is attached to the handle");
+    h->variant = variant;
+    return sac_relayout(h, rlc_h_sac_variant(h) == 2 ? 1 : 0);
+}
+
+int rlc_sac_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {
+    RLC_REQUIRE(h && variant_in_use, "null argument");
+    RLC_NEED_SAC(h);
+    *variant_in_use = rlc_h_sac_variant(h);
+    return 0;
 }
 
 int rlc_sac_enable_grad_taps(rlc_handle* h, int32_t on) {

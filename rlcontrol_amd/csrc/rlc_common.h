@@ -371,6 +371,53 @@ __device__ __forceinline__ float adam_alpha(float lr, float b1p, float b2p) {
     return lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
 }
 
+// column n of a [rows, ncols] weight matrix in either device layout (row-major or tile-blocked, rlc_common.h):
+// at(k0) points at row k0; rows k0+i of the same 16-row block follow at i*step floats.
+struct RlcWCol {
+    const float* p;
+    int step, rowblk, blocked;
+    __device__ __forceinline__ const float* at(int k0) const {
+        return blocked ? p + (size_t)(k0 >> 4) * rowblk + ((k0 & 15) << 2) : p + (size_t)k0 * step;
+    }
+};
+__device__ __forceinline__ RlcWCol rlc_wcol(const float* W, int blocked, int n, int ncols) {
+    RlcWCol w;
+    w.blocked = blocked;
+    if (blocked) {
+        w.p = W + ((n >> 4) << 8) + (((n & 15) >> 2) << 6) + (n & 3);
+        w.step = 4;
+        w.rowblk = ((ncols + 15) >> 4) << 8;
+    } else {
+        w.p = W + n;
+        w.step = ncols;
+        w.rowblk = 0;
+    }
+    return w;
+}
+
+// h_out[n] = relu(bias[n] + sum_k h_in[k] W[k][n]) for one row (B = 1 acting paths), W in either device layout.
+// One thread per output unit, k ascending in one accumulator; the weight column is fetched KC rows at a time so
+// that KC loads are in flight per thread instead of one dependent chain.  No barrier inside.
+__device__ inline void rlc_hidden_forward_row(const float* W, int blocked, const float* bias, const float* h_in, int K,
+                                              int N, float* h_out) {
+    constexpr int KC = 16;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const RlcWCol wcol = rlc_wcol(W, blocked, n, N);
+        float acc = 0.0f;
+        int k0 = 0;
+        for (; k0 + KC <= K; k0 += KC) {     // KC = 16: a chunk never straddles a 16-row block
+            const float* wp = wcol.at(k0);
+            float w[KC];
+#pragma unroll
+            for (int i = 0; i < KC; i++) w[i] = wp[(size_t)i * wcol.step];
+#pragma unroll
+            for (int i = 0; i < KC; i++) acc += h_in[k0 + i] * w[i];
+        }
+        for (; k0 < K; k0++) acc += h_in[k0] * *wcol.at(k0);
+        h_out[n] = fmaxf(acc + bias[n], 0.0f);
+    }
+}
+
 // k distinct uniform logical indices in [0, n) for one agent; one workgroup.
 // dense regime (3k >= n, as in sample_n_k): partial Fisher-Yates over an LDS copy of range(n);
 // sparse regime: one candidate per thread, duplicates (against lower-numbered threads) redrawn

@@ -38,6 +38,21 @@ struct rlc_handle {
     int ro_pending_q8;                   // an evaluation ran after the last update: next step resets OU after acting
 };
 
+// kernel variant in use (1 generic, 2 mfma): the request h->variant (0 auto) resolved against the shape support
+inline int rlc_h_sac_variant(const rlc_handle* h) {
+    if (h->variant == 1 || h->variant == 2) return h->variant;
+    return rlc_sac_mfma_supported(h->sac.d) ? 2 : 1;
+}
+inline int rlc_h_naf_variant(const rlc_handle* h) {
+    if (h->variant == 1 || h->variant == 2) return h->variant;
+    return rlc_naf_mfma_supported(h->naf.d) ? 2 : 1;
+}
+// fused update launch of the variant in use (rlc_api_sac.hip / rlc_api_naf.hip)
+int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
+                            const float* eps_dev, const struct RlcSacRollout* rollout);
+int rlc_h_naf_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
+                            const struct RlcNafRollout* rollout);
+
 // shared helpers (rlc_api.hip)
 int rlc_h_check_agent(const rlc_handle* h, int agent);
 int rlc_h_use_device(const rlc_handle* h);

@@ -65,6 +65,11 @@ struct RlcSacRollout;   // sac_rollout_device.h: {RlcSacDev, RlcEnvDev} in devic
 int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
                           const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
                           const RlcSacRollout* rollout = nullptr);
+// MFMA-tiled fused update (dims must satisfy rlc_sac_mfma_supported; tile-blocked layout)
+bool rlc_sac_mfma_supported(const RlcSacDims& d);
+int rlc_launch_sac_update_mfma(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                               const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
+                               const RlcSacRollout* rollout = nullptr);
 int rlc_launch_sac_eval(const RlcSacDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);
 // one state per agent; sample = 0 mean action, 1 reparameterised sample (eps_dev [n][A] or null -> Philox)
 int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,

@@ -48,10 +48,14 @@ __device__ inline void sac_policy_forward(const RlcSacDims& d, const float* th, 
         L.h1[k] = fmaxf(acc + th[d.pb1 + k], 0.0f);
     }
     __syncthreads();
-    for (int n = tid; n < L2A; n += nthr) {
-        float acc = 0.0f;
-        for (int k = 0; k < L1A; k++) acc += L.h1[k] * th[d.pW2 + (size_t)k * L2A + n];
-        L.h2[n] = fmaxf(acc + th[d.pb2 + n], 0.0f);
+    if (d.blocked) {
+        rlc_hidden_forward_row(th + d.pW2, 1, th + d.pb2, L.h1, L1A, L2A, L.h2);
+    } else {
+        for (int n = tid; n < L2A; n += nthr) {
+            float acc = 0.0f;
+            for (int k = 0; k < L1A; k++) acc += L.h1[k] * th[d.pW2 + (size_t)k * L2A + n];
+            L.h2[n] = fmaxf(acc + th[d.pb2 + n], 0.0f);
+        }
     }
     __syncthreads();
     const int wave = tid / 64, lane = tid % 64;

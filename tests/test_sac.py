@@ -73,19 +73,27 @@ def test_sac_v_loss_broadcast_quirk_q9():
 
 
 # ------------------------------------------------------------------------------------------ GPU
-def _pop(dims, B, n_agents=1, alpha=0.5, cap=2048):
+KERNELS = ["generic", "mfma"]
+
+
+def _pop(dims, B, n_agents=1, alpha=0.5, cap=2048, kernel="auto"):
     from rlcontrol_amd.hip_sac import SACPopulation
     S, A, L1A, L2A, L1C, L2C = dims
-    return SACPopulation(n_agents, S, A, L1A, L2A, L1C, L2C, B, cap, 0.01, -1.0, 1.0, 2.0, 1e-2, 1e-1, alpha,
-                         seeds=list(range(5, 5 + n_agents)))
+    pop = SACPopulation(n_agents, S, A, L1A, L2A, L1C, L2C, B, cap, 0.01, -1.0, 1.0, 2.0, 1e-2, 1e-1, alpha,
+                        seeds=list(range(5, 5 + n_agents)))
+    if kernel != "auto":
+        pop.set_kernel(kernel)
+        assert pop.kernel_in_use() == kernel
+    return pop
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims,B", CASES)
-def test_sac_hip_update_matches_oracle(hip_lib, dims, B):
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dims,B", CASES + [((3, 2, 128, 96, 112, 128), 100), ((8, 1, 200, 160, 144, 176), 64)])
+def test_sac_hip_update_matches_oracle(hip_lib, dims, B, kernel):
     d = SacDims(*dims)
     th = _benign(d, init_params(d, 1))
-    pop = _pop(dims, B)
+    pop = _pop(dims, B, kernel=kernel)
     pop.enable_grad_taps(True)
     pop.set_params(0, th)
     o = SACOracle(d, th, 1e-2, 1e-1, 0.5, 0.01, -1.0, 1.0, 2.0)
@@ -110,12 +118,13 @@ def test_sac_hip_update_matches_oracle(hip_lib, dims, B):
 
 
 @pytest.mark.gpu
-def test_sac_hip_at_reference_initialisation(hip_lib):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_sac_hip_at_reference_initialisation(hip_lib, kernel):
     """Reference initialisation (saturated tanh regime): value-side quantities still agree tightly."""
     dims, B = (3, 1, 128, 128, 128, 128), 32
     d = SacDims(*dims)
     th = init_params(d, 4)
-    pop = _pop(dims, B, alpha=1.0)
+    pop = _pop(dims, B, alpha=1.0, kernel=kernel)
     pop.set_params(0, th)
     o = SACOracle(d, th, 1e-2, 1e-1, 1.0, 0.01, -1.0, 1.0, 2.0)
     rng = np.random.RandomState(9)
@@ -129,11 +138,12 @@ def test_sac_hip_at_reference_initialisation(hip_lib):
 
 
 @pytest.mark.gpu
-def test_sac_hip_replay_path_and_act(hip_lib):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_sac_hip_replay_path_and_act(hip_lib, kernel):
     from oracle.cpu_baseline import synthetic_pendulum_replay
     dims, B, N = (3, 1, 128, 128, 128, 128), 32, 2048
     d = SacDims(*dims)
-    pop = _pop(dims, B, n_agents=2, cap=N)
+    pop = _pop(dims, B, n_agents=2, cap=N, kernel=kernel)
     ths = [_benign(d, init_params(d, 10 + i)) for i in range(2)]
     s, a, r, s2, g = synthetic_pendulum_replay(N, 0)
     for i in range(2):
@@ -195,14 +205,15 @@ def test_sac_dropin_agent_runs_on_pendulum(hip_lib):
 
 
 @pytest.mark.gpu
-def test_sac_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_sac_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib, kernel):
     """Fused path with the DEVICE sampler (host eps): the indices come from the Philox stream that
     oracle/philox.py restates bit for bit, so K updates in one launch must match the oracle fed with them."""
     from oracle import philox
     from oracle.cpu_baseline import synthetic_pendulum_replay
     dims, B, N, K = (3, 1, 128, 128, 128, 128), 32, 2048, 4
     d = SacDims(*dims)
-    pop = _pop(dims, B, cap=N)                 # seeds = [5]
+    pop = _pop(dims, B, cap=N, kernel=kernel)  # seeds = [5]
     th = _benign(d, init_params(d, 21))
     s, a, r, s2, g = synthetic_pendulum_replay(N, 0)
     pop.set_params(0, th)
@@ -217,3 +228,28 @@ def test_sac_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib
         assert _rel(pop.last_tap(0, k), t[k]) < 1e-4, k
     assert _rel(pop.get_blob(0, "theta_target"), o.theta_t) < 1e-4
     pop.close()
+
+
+@pytest.mark.gpu
+def test_sac_kernel_switch_repacks_weights_and_optimizer_state(hip_lib):
+    """generic <-> mfma changes the device layout (row-major <-> tile-blocked): blobs survive the round trip and the
+    two kernels continue the same trajectory to summation-order accuracy."""
+    dims, B = (3, 1, 128, 128, 128, 128), 100
+    d = SacDims(*dims)
+    th = _benign(d, init_params(d, 7))
+    rng = np.random.RandomState(5)
+    batches = [_batch(rng, B, 3, 1) for _ in range(4)]
+    pa, pb = _pop(dims, B, kernel="mfma"), _pop(dims, B, kernel="generic")
+    for p in (pa, pb):
+        p.set_params(0, th)
+    for k, (s, a, s2, r, g, eps) in enumerate(batches):
+        pa.update_batch(0, s, a, s2, r, g, eps=eps)
+        pb.update_batch(0, s, a, s2, r, g, eps=eps)
+        if k == 1:                                   # swap the kernels mid-trajectory
+            before = {w: pa.get_blob(0, w) for w in ("theta", "theta_target", "adam_m", "adam_v")}
+            pa.set_kernel("generic"); pb.set_kernel("mfma")
+            for w, v in before.items():
+                assert np.array_equal(pa.get_blob(0, w), v), w
+    for w in ("theta", "theta_target", "adam_m", "adam_v"):
+        assert _rel(pa.get_blob(0, w), pb.get_blob(0, w)) < 2e-4, w
+    pa.close(); pb.close()
