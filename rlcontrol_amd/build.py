@@ -21,6 +21,7 @@ SAC_VARIANTS = [(mt, ntw, ad) for ad in (1, 2) for ntw in (1, 2) for mt in (2, 4
 if FAST:
     MFMA_VARIANTS = [(7, 1)]
     SAC_VARIANTS = [(7, 1, 1)]
+NAF_VARIANTS = [(7, 2, 2)] if FAST else [(mt, ntw, ad) for ad in (1, 2) for ntw in (1, 2) for mt in (2, 4, 7, 8)]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-Wno-unused-result"] + (["-DRLC_STAMPS"] if STAMPS else [])
 if os.environ.get("RLC_FAST_BUILD", "0") == "1":
     CFLAGS.append("-DRLC_ONLY_7_1")
@@ -43,6 +44,9 @@ def _units():
                       ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
     for mt, ntw, ad in SAC_VARIANTS:
         units.append((os.path.join(CSRC, "sac_mfma_inst.hip"), os.path.join(OBJ, "sac_mfma_%d_%d_%d.o" % (mt, ntw, ad)),
+                      ["-DRLC_MT=%d" % mt, "-DRLC_NTW=%d" % ntw, "-DRLC_AD=%d" % ad]))
+    for mt, ntw, ad in NAF_VARIANTS:
+        units.append((os.path.join(CSRC, "naf_mfma_inst.hip"), os.path.join(OBJ, "naf_mfma_%d_%d_%d.o" % (mt, ntw, ad)),
                       ["-DRLC_MT=%d" % mt, "-DRLC_NTW=%d" % ntw, "-DRLC_AD=%d" % ad]))
     return units
 

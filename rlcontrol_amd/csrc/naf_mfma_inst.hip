@@ -1,0 +1,15 @@
+// naf_mfma_inst.hip -- one instantiation of the MFMA NAF kernel per translation unit
+// (compiled once per (RLC_MT, RLC_NTW, RLC_AD) triple by rlcontrol_amd/build.py so the variants build in parallel).
+#include "naf_mfma_kernel.h"
+
+#ifndef RLC_MT
+#error "compile with -DRLC_MT=<M tiles> -DRLC_NTW=<N tiles per wave> -DRLC_AD=<action dim>"
+#endif
+
+#define RLC_CAT_(a, b, c) rlc_naf_mfma_launch_##a##_##b##_##c
+#define RLC_CAT(a, b, c) RLC_CAT_(a, b, c)
+
+int RLC_CAT(RLC_MT, RLC_NTW, RLC_AD)(const RlcNafDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                                     const long long* idx_dev, int grad_taps, hipStream_t st, const RlcNafRollout* rollout) {
+    return naf_launch_t<RLC_MT, RLC_NTW, RLC_AD>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout);
+}

@@ -59,20 +59,30 @@ def test_naf_loss_is_a_sum_not_a_mean():
 
 
 # ------------------------------------------------------------------------------------------ GPU
-def _pop(dims, B, n_agents=1, cap=2048, lr=1e-3):
+KERNELS = ["generic", "mfma"]
+
+
+def _pop(dims, B, n_agents=1, cap=2048, lr=1e-3, kernel="auto"):
     from rlcontrol_amd.hip_naf import NAFPopulation
     S, A, L1, L2 = dims
+    if kernel == "mfma" and A > 2:
+        pytest.skip("the MFMA NAF kernel covers action_dim <= 2 (the generic kernel takes the rest)")
     smin, smax, amax = _bounds(S, A)
-    return NAFPopulation(n_agents, S, A, L1, L2, B, cap, 0.01, smin, smax, amax, lr, seeds=list(range(3, 3 + n_agents)))
+    pop = NAFPopulation(n_agents, S, A, L1, L2, B, cap, 0.01, smin, smax, amax, lr, seeds=list(range(3, 3 + n_agents)))
+    if kernel != "auto":
+        pop.set_kernel(kernel)
+        assert pop.kernel_in_use() == kernel
+    return pop
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims,B", CASES)
-def test_naf_hip_update_matches_oracle(hip_lib, dims, B):
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dims,B", CASES + [((8, 1, 128, 96), 100), ((4, 2, 256, 144), 48)])
+def test_naf_hip_update_matches_oracle(hip_lib, dims, B, kernel):
     d = NafDims(*dims)
     th = init_params(d, 2)
     smin, smax, amax = _bounds(dims[0], dims[1])
-    pop = _pop(dims, B)
+    pop = _pop(dims, B, kernel=kernel)
     pop.enable_grad_taps(True)
     pop.set_params(0, th)
     o = NAFOracle(d, th, 1e-3, 0.01, smin, smax, amax)
@@ -96,11 +106,12 @@ def test_naf_hip_update_matches_oracle(hip_lib, dims, B):
 
 
 @pytest.mark.gpu
-def test_naf_hip_replay_path_act_and_agent(hip_lib):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_naf_hip_replay_path_act_and_agent(hip_lib, kernel):
     dims, B, N = (8, 2, 200, 200), 32, 1500
     d = NafDims(*dims)
     smin, smax, amax = _bounds(8, 2)
-    pop = _pop(dims, B, n_agents=2, cap=N)
+    pop = _pop(dims, B, n_agents=2, cap=N, kernel=kernel)
     rng = np.random.RandomState(5)
     data = (rng.uniform(-3, 3, (N, 8)), rng.uniform(-2, 2, (N, 2)), rng.uniform(-16, 0, N), rng.uniform(-3, 3, (N, 8)),
             np.full(N, 0.99))
@@ -154,14 +165,15 @@ def test_naf_hip_replay_path_act_and_agent(hip_lib):
 
 
 @pytest.mark.gpu
-def test_naf_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_naf_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib, kernel):
     """Fused path with the DEVICE sampler: same Philox stream as oracle/philox.py, so K updates in one launch
     must match the oracle fed with the minibatches that stream selects."""
     from oracle import philox
     dims, B, N, K = (8, 2, 200, 200), 64, 2048, 4
     d = NafDims(*dims)
     smin, smax, amax = _bounds(*dims[:2])
-    pop = _pop(dims, B, cap=N, lr=1e-4)        # seeds = [3]
+    pop = _pop(dims, B, cap=N, lr=1e-4, kernel=kernel)        # seeds = [3]
     th = init_params(d, 17)
     rng = np.random.RandomState(6)
     s, a, s2 = rng.uniform(-3, 3, (N, 8)), rng.uniform(-1, 1, (N, 2)), rng.uniform(-3, 3, (N, 8))
@@ -178,3 +190,28 @@ def test_naf_device_sampler_equals_oracle_on_the_same_philox_minibatches(hip_lib
         assert _rel(pop.last_tap(0, k), t[k]) < 1e-4, k
     assert _rel(pop.get_blob(0, "theta_target"), o.theta_t) < 1e-4
     pop.close()
+
+
+@pytest.mark.gpu
+def test_naf_kernel_switch_repacks_weights_and_optimizer_state(hip_lib):
+    """generic <-> mfma changes the device layout (row-major <-> tile-blocked): blobs survive the round trip and the
+    two kernels continue the same trajectory to summation-order accuracy."""
+    dims, B = (8, 2, 200, 200), 100
+    d = NafDims(*dims)
+    th = init_params(d, 9)
+    rng = np.random.RandomState(2)
+    batches = [_batch(rng, B, 8, 2) for _ in range(4)]
+    pa, pb = _pop(dims, B, kernel="mfma", lr=1e-4), _pop(dims, B, kernel="generic", lr=1e-4)
+    for p in (pa, pb):
+        p.set_params(0, th)
+    for k, (s, a, s2, r, g) in enumerate(batches):
+        pa.update_batch(0, s, a, s2, r, g)
+        pb.update_batch(0, s, a, s2, r, g)
+        if k == 1:
+            before = {w: pa.get_blob(0, w) for w in ("theta", "theta_target", "adam_m", "adam_v")}
+            pa.set_kernel("generic"); pb.set_kernel("mfma")
+            for w, v in before.items():
+                assert np.array_equal(pa.get_blob(0, w), v), w
+    for w in ("theta", "theta_target", "adam_m"):
+        assert _rel(pa.get_blob(0, w), pb.get_blob(0, w)) < 2e-4, w
+    pa.close(); pb.close()
