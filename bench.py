@@ -21,6 +21,9 @@ The JSON line also carries
                 intensity > 19.7 ridge), achieved = 73.2 MFLOP x updates per launch / HIP-event launch time
   roofline_hbm  the same launch priced in algorithmic HBM bytes (2,634,064 B per update) vs 8 TB/s
   cpu_baseline  the reference-structured CPU port (oracle/) timed on this host, rank 0 at N=1 only
+  sac, naf      (N=1 only) the same measurement for BASELINE configs[2] / [3]: SoftActorCritic (S=3 A=1 L=128) and
+                NAF (S=8 A=2 L=200) fused update kernels, 256 agents x 1e6-record replays, each with its own
+                flop_per_update and roofline fraction; the DDPG headline stays `value`
 """
 import argparse
 import json
@@ -40,6 +43,14 @@ FLOP_PER_UPDATE = 73.2e6          # 366,000 MAC/sample * 2 * 100
 BYTES_PER_UPDATE = 2634064.0      # params+Adam+target read+write, + 3,600 B gather
 PEAK_FP32_MATRIX = 157.3e12       # MI355X_MICROARCH.md: v_mfma_f32_* dense peak = fp32 vector peak
 PEAK_HBM = 8.0e12                 # MI355X_MICROARCH.md: HBM3E spec peak
+# MAC counts per sample with every contraction done once (the Q hidden contraction
+# of SAC is shared by Q(s,a) and Q(s,pi)); params x {theta, target, Adam m, v} read + written, + the gather
+SAC_SHAPE = dict(S=3, A=1, L=128)
+SAC_FLOP_PER_UPDATE = 168832 * 2 * 100.0
+SAC_BYTES_PER_UPDATE = 51716 * 4 * 4 * 2 + 100 * (2 * 3 + 1 + 2) * 4.0
+NAF_SHAPE = dict(S=8, A=2, L=200)
+NAF_FLOP_PER_UPDATE = 288600 * 2 * 100.0
+NAF_BYTES_PER_UPDATE = 83406 * 4 * 4 * 2 + 100 * (2 * 8 + 2 + 2) * 4.0
 
 
 def synthetic_pendulum_replay(n, seed=0):
@@ -54,6 +65,14 @@ def synthetic_pendulum_replay(n, seed=0):
     thd2 = np.clip(thd2, -8.0, 8.0)
     s2 = np.stack([np.cos(th2), np.sin(th2), thd2], 1)
     return (s.astype(np.float32), a[:, None].astype(np.float32), r.astype(np.float64), s2.astype(np.float32),
+            np.full(n, 0.99, np.float64))
+
+
+def synthetic_uniform_replay(n, sdim, adim, seed=0):
+    """U-distributed replay of the same N for the SAC / NAF shapes"""
+    rng = np.random.RandomState(seed)
+    return (rng.uniform(-1, 1, (n, sdim)).astype(np.float32), rng.uniform(-1, 1, (n, adim)).astype(np.float32),
+            rng.uniform(-16, 0, n).astype(np.float64), rng.uniform(-1, 1, (n, sdim)).astype(np.float32),
             np.full(n, 0.99, np.float64))
 
 
@@ -82,10 +101,11 @@ def _cpu_port_run(seconds, records):
     return n, time.perf_counter() - t0
 
 
-def cpu_baseline(seconds=15.0, records=200000, all_cores=True):
+def cpu_baseline(seconds=15.0, records=REPLAY_N, all_cores=True):
     """The CPU baseline beside the GPU number: (i) one core = the reference's own deployment unit
     (one INDEX per process), the primary figure; (ii) one independent process per host core (one INDEX each).
-    Runs BEFORE anything touches the GPU: the workers of (ii) are child processes."""
+    Same workload as the GPU leg (a 1e6-record replay per process).  Runs BEFORE anything touches the GPU: the
+    workers of (ii) are child processes."""
     n, dt = _cpu_port_run(seconds, records)
     out = {"value": n / dt, "unit": "gradient updates/s", "cores": 1, "kind": "port",
            "sample": "%d updates (%.1f s) on a %d-record list replay; oracle/ddpg_oracle.c + reference-"
@@ -97,7 +117,7 @@ def cpu_baseline(seconds=15.0, records=200000, all_cores=True):
                "--cpu-records", str(records)]
         procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
         rates = []
-        deadline = time.time() + seconds + 120.0
+        deadline = time.time() + seconds + 180.0
         for pr in procs:
             try:
                 o, _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
@@ -110,21 +130,128 @@ def cpu_baseline(seconds=15.0, records=200000, all_cores=True):
     return out
 
 
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+
+
 def pmc_traffic(n_agents, updates_per_launch, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, scripts/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for 16 B/lane streams -> an upper bound, the dword-load share being uncalibrated).  Counters cannot be read
-    inside a timed run, so this is the measurement of the same command line taken when the kernel last changed;
-    null when the configuration differs from the measured one."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            m = json.load(f)
-    except (OSError, ValueError):
-        return None
-    if kernel != "mfma" or m.get("agents") != n_agents or m.get("updates_per_launch") != updates_per_launch:
-        return None
-    return m.get("traffic_bytes_per_launch_upper")
+    inside a timed run, so this is the measurement of the same command line taken when the kernel last changed
+    (scaled per update when the launch length differs); returns (bytes per launch | None, source file | None)."""
+    for name in PMC_FILES:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as f:
+                m = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if kernel != "mfma" or m.get("agents") != n_agents:
+            continue
+        per_update = m.get("traffic_bytes_per_update_upper")
+        if per_update is None and m.get("traffic_bytes_per_launch_upper") is not None:
+            per_update = m["traffic_bytes_per_launch_upper"] / float(m["agents"] * m["updates_per_launch"])
+        if per_update is None:
+            continue
+        return per_update * n_agents * updates_per_launch, "profiles/" + name
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the timed region and its bookkeeping (shared by every workload; tests/test_distributed_cpu.py drives it with a
+# stub population under gloo)
+# ------------------------------------------------------------------------------------------------------------
+def measure(pop, updates_per_step, steps, warmup, dist=None, device_sync=None):
+    """`warmup` untimed steps, then EXACTLY `steps` timed steps bracketed by (population sync + device sync +
+    barrier) on both sides.  Returns (this rank's wall seconds, HIP-event milliseconds on the population's stream)."""
+    def sync_all():
+        pop.sync()
+        if device_sync is not None:
+            device_sync()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(warmup):
+        pop.update(updates_per_step)
+    sync_all()
+    t0 = time.perf_counter()
+    pop.timer_begin()
+    for _ in range(steps):
+        pop.update(updates_per_step)
+    ev_ms = pop.timer_end()
+    sync_all()
+    return time.perf_counter() - t0, ev_ms
+
+
+def reduce_over_ranks(dt, result, dist=None, world=1, device="cpu"):
+    """MAX of the wall time over ranks + the one collective of the path: an all-gather of each rank's small result
+    vector (after the timed region).  Returns (dt_max, [result of rank 0, 1, ...])."""
+    import torch
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    res = torch.tensor([float(result)], dtype=torch.float64, device=device)
+    if dist is None or world == 1:
+        return float(t.item()), [float(res.item())]
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gathered = [torch.zeros_like(res) for _ in range(world)]
+    dist.all_gather(gathered, res)
+    return float(t.item()), [float(g.item()) for g in gathered]
+
+
+def aggregate_value(world, agents, updates_per_step, steps, dt_max):
+    """whole-job updates/s: every rank ran agents * updates_per_step * steps updates in at most dt_max seconds"""
+    return world * agents * updates_per_step * steps / dt_max
+
+
+def roofline_record(flop_per_update, bytes_per_update, updates_per_launch, launch_s):
+    ach_flops = flop_per_update * updates_per_launch / launch_s
+    ach_bytes = bytes_per_update * updates_per_launch / launch_s
+    return ({"bound": "mfma", "achieved": ach_flops / 1e12, "peak": PEAK_FP32_MATRIX / 1e12, "unit": "TFLOP/s",
+             "frac": ach_flops / PEAK_FP32_MATRIX, "kernel_ms_per_launch": launch_s * 1e3,
+             "flop_per_update": flop_per_update},
+            {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+             "frac": ach_bytes / PEAK_HBM, "bytes_per_update": bytes_per_update})
+
+
+def _fill_from_host(pop, host, torch):
+    dev = [torch.from_numpy(x).cuda() for x in host]
+    torch.cuda.synchronize()
+    pop.replay_fill_all_dev(host[0].shape[0], dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(),
+                            dev[3].data_ptr(), dev[4].data_ptr())
+    pop.sync()
+    del dev
+
+
+def side_record(algo, NA, U, steps, warmup, torch, device):
+    """BASELINE configs[2] / [3]: the SAC-v1 / NAF fused update kernels on 256 agents x 1e6-record replays."""
+    seeds = np.arange(NA, dtype=np.uint64) + 1
+    if algo == "sac":
+        from rlcontrol_amd.hip_sac import SACPopulation, init_params
+        L = SAC_SHAPE["L"]
+        pop = SACPopulation(NA, SAC_SHAPE["S"], SAC_SHAPE["A"], L, L, L, L, B, REPLAY_N, 0.01, -8.0, 8.0, 2.0, 1e-3, 1e-3,
+                            0.2, seeds=seeds, device=device)
+        for i in range(NA):
+            pop.set_params(i, init_params(SAC_SHAPE["S"], SAC_SHAPE["A"], L, L, L, L, int(seeds[i])))
+        host = synthetic_uniform_replay(REPLAY_N, SAC_SHAPE["S"], SAC_SHAPE["A"])
+        flop, byts = SAC_FLOP_PER_UPDATE, SAC_BYTES_PER_UPDATE
+        wl = "SoftActorCritic (SAC-v1) on synthetic replay (1e6 transitions/agent), obs=3 act=1 l1=l2=128 batch=100"
+    else:
+        from rlcontrol_amd.hip_naf import NAFPopulation, init_params
+        L = NAF_SHAPE["L"]
+        pop = NAFPopulation(NA, NAF_SHAPE["S"], NAF_SHAPE["A"], L, L, B, REPLAY_N, 0.01, -np.ones(8) * 10, np.ones(8) * 10,
+                            np.ones(2), 1e-3, seeds=seeds, device=device)
+        for i in range(NA):
+            pop.set_params(i, init_params(NAF_SHAPE["S"], NAF_SHAPE["A"], L, L, int(seeds[i])))
+        host = synthetic_uniform_replay(REPLAY_N, NAF_SHAPE["S"], NAF_SHAPE["A"])
+        flop, byts = NAF_FLOP_PER_UPDATE, NAF_BYTES_PER_UPDATE
+        wl = "NAF on synthetic replay (1e6 transitions/agent), obs=8 act=2 l1=l2=200 batch=100"
+    _fill_from_host(pop, host, torch)
+    dt, ev_ms = measure(pop, U, steps, warmup, None, torch.cuda.synchronize)
+    roof, roof_hbm = roofline_record(flop, byts, NA * U, ev_ms * 1e-3 / steps)
+    rec = {"value": aggregate_value(1, NA, U, steps, dt), "unit": "gradient updates/s", "workload": wl,
+           "agents_per_gpu": NA, "updates_per_step": U, "steps": steps, "kernel": pop.kernel_in_use(),
+           "ms_per_step": dt * 1e3 / steps, "updates_timed_per_agent": U * steps, "roofline": roof, "roofline_hbm": roof_hbm}
+    pop.close()
+    return rec
 
 
 def main():
@@ -133,11 +260,14 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--agents", type=int, default=256, help="independent agents per GPU (one per CU)")
-    ap.add_argument("--updates-per-step", type=int, default=32, help="updates of every agent per launch")
+    ap.add_argument("--updates-per-step", type=int, default=320,
+                    help="updates of every agent per launch (320 x 20 steps = 6,400 timed updates per agent, > 2 s)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-records", action="store_true", help="skip the SAC / NAF sub-records")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--cpu-records", type=int, default=200000)
+    ap.add_argument("--cpu-records", type=int, default=REPLAY_N)
     ap.add_argument("--cpu-worker", action="store_true", help="internal: one process of the all-cores CPU baseline")
     args = ap.parse_args()
     if args.cpu_worker:
@@ -158,11 +288,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)          # before any other GPU call; no re-exec anywhere in this file
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     import __graft_entry__ as entry
     if rank == 0 or world == 1:
@@ -181,49 +314,24 @@ def main():
     for i in range(NA):
         pop.set_params(i, init_params(S, A_DIM, H, H, H, int(seeds[i])))
     # synthetic replay -> HBM (torch is only the allocator/copy engine here), then into every agent's ring
-    host = synthetic_pendulum_replay(REPLAY_N, 0)
-    dev = [torch.from_numpy(x).cuda() for x in host]
-    torch.cuda.synchronize()
-    pop.replay_fill_all_dev(REPLAY_N, dev[0].data_ptr(), dev[1].data_ptr(), dev[2].data_ptr(), dev[3].data_ptr(),
-                            dev[4].data_ptr())
-    pop.sync()
-    del dev
+    _fill_from_host(pop, synthetic_pendulum_replay(REPLAY_N, 0), torch)
 
-    def sync_all():
-        pop.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        pop.update(U)
-    sync_all()
-    t0 = time.perf_counter()
-    pop.timer_begin()
-    for _ in range(args.steps):
-        pop.update(U)
-    ev_ms = pop.timer_end()
-    sync_all()
-    dt = time.perf_counter() - t0
-
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    result = torch.tensor([float(np.mean(pop.last_tap(0, "q")))], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(result) for _ in range(world)]
-        dist.all_gather(gathered, result)       # the one collective: per-rank results, after the timed region
-    dt_max = float(t.item())
+    dt, ev_ms = measure(pop, U, args.steps, args.warmup, dist, torch.cuda.synchronize)
+    red_dev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
+    dt_max, gathered = reduce_over_ranks(dt, float(np.mean(pop.last_tap(0, "q"))), dist, world, red_dev)
     kernel = pop.kernel_in_use()
+    pop.close()
 
     if rank == 0:
-        traffic = pmc_traffic(NA, U, kernel)
-        updates_per_launch = NA * U
-        launch_s = ev_ms * 1e-3 / args.steps
-        ach_flops = FLOP_PER_UPDATE * updates_per_launch / launch_s
-        ach_bytes = BYTES_PER_UPDATE * updates_per_launch / launch_s
+        traffic, traffic_source = pmc_traffic(NA, U, kernel)
+        roof, roof_hbm = roofline_record(FLOP_PER_UPDATE, BYTES_PER_UPDATE, NA * U, ev_ms * 1e-3 / args.steps)
+        roof["traffic"] = traffic
+        roof["traffic_source"] = traffic_source      # a committed earlier profile of this command, not an in-run counter
+        roof_hbm["traffic"] = traffic
+        roof_hbm["traffic_source"] = traffic_source
         out = {
             "metric": "gradient updates/sec/GPU (batch=100), Pendulum-shaped DDPG",
-            "value": world * NA * U * args.steps / dt_max,
+            "value": aggregate_value(world, NA, U, args.steps, dt_max),
             "unit": "gradient updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max * 1e3 / args.steps,
@@ -232,17 +340,20 @@ def main():
             "config": {"workload": "DDPG on synthetic Pendulum-shaped replay (1e6 transitions/agent), obs=3 act=1 "
                                    "l1=l2=200 batch=100, fused HIP replay-sample+gather+update kernel",
                        "agents_per_gpu": NA, "updates_per_step": U, "kernel": kernel,
+                       "updates_timed_per_agent": U * args.steps, "updates_warmup_per_agent": U * args.warmup,
                        "per_gpu_value": NA * U * args.steps / dt_max,
-                       "parallelism": "independent seeds x%d per GPU, x%d GPUs" % (NA, world)},
-            "roofline": {"bound": "mfma", "achieved": ach_flops / 1e12, "peak": PEAK_FP32_MATRIX / 1e12,
-                         "unit": "TFLOP/s", "frac": ach_flops / PEAK_FP32_MATRIX, "traffic": traffic,
-                         "kernel_ms_per_launch": launch_s * 1e3, "flop_per_update": FLOP_PER_UPDATE},
-            "roofline_hbm": {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                             "frac": ach_bytes / PEAK_HBM, "traffic": traffic, "bytes_per_update": BYTES_PER_UPDATE},
+                       "parallelism": "independent seeds x%d per GPU, x%d GPUs" % (NA, world),
+                       "per_rank_result": gathered},
+            "roofline": roof,
+            "roofline_hbm": roof_hbm,
         }
         out["cpu_baseline"] = cpu_base
+        if world == 1 and not args.no_side_records:
+            # BASELINE configs[2], [3] on the same box, same agent count and replay size (extra keys; `value` is DDPG)
+            side_U = max(1, U // 4)
+            for algo in ("sac", "naf"):
+                out[algo] = side_record(algo, NA, side_U, args.steps, args.warmup, torch, local_rank)
         print(json.dumps(out))
-    pop.close()
     if dist is not None:
         dist.destroy_process_group()
 

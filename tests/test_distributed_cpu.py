@@ -139,3 +139,73 @@ def test_main_under_two_ranks_writes_one_complete_pickle(tmp_path):
                       "train_episode_rewards"):
                 assert np.array_equal(np.asarray(ra[k]), np.asarray(rb[k])), k
             assert ra["total_train_episodes"] == rb["total_train_episodes"]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bench.py's N > 1 branch: barrier-bracketed timed region, MAX over ranks, the one all-gather, whole-job value
+# ---------------------------------------------------------------------------------------------------------
+class _StubPopulation(object):
+    """what bench.measure() needs from a population: update / sync / timer; rank-dependent step time"""
+    def __init__(self, seconds_per_update):
+        self.dt, self.updates, self.t0 = seconds_per_update, 0, None
+
+    def update(self, n):
+        import time
+        time.sleep(self.dt * n)
+        self.updates += n
+
+    def sync(self):
+        pass
+
+    def timer_begin(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def timer_end(self):
+        import time
+        return (time.perf_counter() - self.t0) * 1e3
+
+
+def _bench_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import json
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pop = _StubPopulation(0.002 * (1 + rank))              # rank 1 is twice as slow: it sets the MAX
+    dt, ev_ms = bench.measure(pop, 5, steps=4, warmup=2, dist=dist, device_sync=None)
+    dt_max, gathered = bench.reduce_over_ranks(dt, 10.0 + rank, dist, world, "cpu")
+    with open(os.path.join(out, "r%d.json" % rank), "w") as f:
+        json.dump({"dt": dt, "ev_ms": ev_ms, "dt_max": dt_max, "gathered": gathered, "updates": pop.updates,
+                   "value": bench.aggregate_value(world, 3, 5, 4, dt_max)}, f)
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_bookkeeping_under_gloo(tmp_path):
+    import json
+    ctx = mp.get_context("spawn")
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    r0, r1 = (json.load(open(tmp_path / ("r%d.json" % r))) for r in range(2))
+    assert r0["updates"] == r1["updates"] == (2 + 4) * 5            # warm-up steps run, exactly K steps timed
+    assert r0["dt_max"] == r1["dt_max"] >= max(r0["dt"], r1["dt"]) - 1e-9       # MAX over ranks, same on every rank
+    assert r1["dt"] >= 4 * 5 * 0.004 and r0["dt"] >= r1["dt"] - 0.02           # the barrier holds rank 0 for the slow rank
+    assert r0["ev_ms"] < r1["ev_ms"]                                 # per-rank kernel time is NOT what value uses
+    assert r0["gathered"] == r1["gathered"] == [10.0, 11.0]           # the one collective: per-rank results, rank order
+    assert abs(r0["value"] - 2 * 3 * 5 * 4 / r0["dt_max"]) < 1e-6     # whole-job units / max time
+
+
+def test_bench_single_rank_reduce_is_identity():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.reduce_over_ranks(0.5, 7.0) == (0.5, [7.0])
+    assert bench.aggregate_value(1, 256, 32, 20, 2.0) == 256 * 32 * 20 / 2.0
+    roof, hbm = bench.roofline_record(73.2e6, 2634064.0, 256 * 32, 10.6e-3)
+    assert abs(roof["frac"] - 73.2e6 * 8192 / 10.6e-3 / 157.3e12) < 1e-12 and roof["bound"] == "mfma"
+    assert abs(hbm["achieved"] - 2634064.0 * 8192 / 10.6e-3 / 1e9) < 1e-6
