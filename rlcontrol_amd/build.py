@@ -25,6 +25,7 @@ NAF_VARIANTS = [(7, 2, 2)] if FAST else [(mt, ntw, ad) for ad in (1, 2) for ntw 
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-Wno-unused-result"] + (["-DRLC_STAMPS"] if STAMPS else [])
 if os.environ.get("RLC_FAST_BUILD", "0") == "1":
     CFLAGS.append("-DRLC_ONLY_7_1")
+CFLAGS += os.environ.get("RLC_EXTRA_CFLAGS", "").split()      # developer loop: A/B switches (-DRLC_...)
 
 
 def _hipcc():

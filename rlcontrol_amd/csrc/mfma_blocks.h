@@ -90,6 +90,14 @@ struct BlkLds {
 
 struct NoExtra {};
 
+// Adam on the small tensors (first layer, a concat layer's extra rows): the hardware-sqrt/rcp form like the big
+// matrices' epilogue unless the build asks for the IEEE-exact expansions
+#ifdef RLC_ADAM_SMALL_EXACT
+#define RLC_ADAM_SMALL adam_step
+#else
+#define RLC_ADAM_SMALL adam_step_fast
+#endif
+
 // MT: M tiles (batch rows / 16); NTW: N tiles per wave (1: widths <= 128, 2: widths <= 256); MSTRIDE: mask row bytes;
 // LERP: target update written (1-tau)*t + tau*w (sac_network.py:72-73) instead of t + tau*(w - t)
 // (hydra_ddpg_network.py:29, naf_network.py:62-63)
@@ -131,19 +139,24 @@ struct Blk {
     }
     template <int SP>
     __device__ __forceinline__ void trunk_t(const float* W1, const float* b1, const lds_f32* xs) {
-        // 256 column slots x 2 row halves
-        const int half = tid >> 8;
-        for (int k = tid & 255; k < LDH; k += 256) {
-            float w[SP];
-            float bias = 0.0f;
-            const bool live = k < H1;
+        // lane = a quad of 4 adjacent columns (its S x 4 weights and 4 biases stay in registers), wave w = rows
+        // w, w+8, ...: per row one broadcast read of the state and ONE 16-byte store of four activations
+        // (a quarter of the LDS store instructions of the one-column-per-thread form; same i-order per element)
+        for (int q = lane; 4 * q < LDH; q += 64) {
+            f32x4 w[SP], bias;
 #pragma unroll
-            for (int i = 0; i < SP; i++) w[i] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
-            if (live) bias = b1[k];
-#pragma unroll 4
-            for (int b = half * (MB / 2); b < (half + 1) * (MB / 2); b++) {
+            for (int e = 0; e < 4; e++) {
+                const int k = 4 * q + e;
+                const bool live = k < H1;
+#pragma unroll
+                for (int i = 0; i < SP; i++) w[i][e] = (live && i < S) ? W1[i * H1 + k] : 0.0f;
+                bias[e] = live ? b1[k] : 0.0f;
+            }
+            const bool live4[4] = {4 * q < H1, 4 * q + 1 < H1, 4 * q + 2 < H1, 4 * q + 3 < H1};
+#pragma unroll 2
+            for (int b = wave; b < MB; b += kWaves) {
                 const f32x4 x0 = *reinterpret_cast<const lds_f32x4*>(&xs[b * SMAX]);
-                float acc = 0.0f;      // same i-order as the scalar form; padded lanes multiply by w = 0
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < 4; i++) acc += x0[i] * w[i];
                 if (SP > 4) {
@@ -151,8 +164,10 @@ struct Blk {
 #pragma unroll
                     for (int i = 0; i < 4; i++) acc += x1[i] * w[(SP > 4 ? 4 : 0) + i];
                 }
-                acc = fmaxf(acc + bias, 0.0f);
-                L.hbuf[b * LDH + k] = (live && b < B) ? acc : 0.0f;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = (live4[e] && b < B) ? fmaxf(acc[e] + bias[e], 0.0f) : 0.0f;
+                *reinterpret_cast<lds_f32x4*>(&L.hbuf[b * LDH + 4 * q]) = o;
             }
         }
     }
@@ -170,7 +185,7 @@ struct Blk {
     // MT ds_read_b128 + 4*NOWN global_load_dword + 4*MT*NOWN MFMAs and little else.
     // ---------------------------------------------------------------------------------------
     template <int NOWN>
-    __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB) {
+    __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB, bool tail8) {
         const float* wp = W + ((size_t)(NTW * wave) << 8) + (((((c >> 2) << 4) + 4 * g) << 2) + (c & 3));
         const size_t wstep = (size_t)NT << 8;                       // floats between block rows
         const lds_f32* ap = L.hbuf + c * LDH + 4 * g;
@@ -197,17 +212,51 @@ struct Blk {
         loadB(b0, 0);
         loadA(a0, 0);
         int ch = 0;
+        // Branch-free body (the prefetch index is clamped: an even chunk count re-reads its last chunk once) so that
+        // both halves form ONE scheduling region, pinned by sched_group_barrier to: the 4*NOWN weight loads of the
+        // next chunk first, then one A-fragment read per 4*NOWN MFMAs -- every load is issued a whole chunk
+        // (4*MT*NOWN MFMAs) before its first use instead of wherever the scheduler sinks it.
+        auto pin = [&]() {
+            __builtin_amdgcn_sched_group_barrier(0x020, 4 * NOWN, 0);          // VMEM read
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NOWN, 0);      // MFMA
+            }
+        };
         for (; ch + 2 <= KB; ch += 2) {
             loadB(b1, ch + 1);
             loadA(a1, ch + 1);
             mac(a0, b0);
-            if (ch + 2 < KB) {          // wave-uniform
-                loadB(b0, ch + 2);
-                loadA(a0, ch + 2);
-            }
+            pin();
+            const int nx = ch + 2 < KB ? ch + 2 : KB - 1;
+            loadB(b0, nx);
+            loadA(a0, nx);
             mac(a1, b1);
+            pin();
         }
         if (ch < KB) mac(a0, b0);      // odd chunk count: the last chunk is already loaded
+        if (tail8) {
+            // K = 16 KB + 8: the last 8 k's in TWO steps instead of a zero-padded chunk of four -- lane group g takes
+            // k = 16 KB + 2g + s (an 8-byte read of hbuf, two weight dwords per tile)
+            const lds_f32* at = L.hbuf + c * LDH + 16 * KB + 2 * g;
+            const float* wt = W + ((size_t)(NTW * wave) << 8) + (size_t)KB * wstep + (((((c >> 2) << 4) + 2 * g) << 2) + (c & 3));
+            float bt[NOWN][2];
+#pragma unroll
+            for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) bt[i][s2] = wt[(i << 8) + 4 * s2];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) av[mt] = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * mt * LDH);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+        }
     }
 
     __device__ __forceinline__ void fwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int N, int K) {
@@ -220,12 +269,13 @@ struct Blk {
         const long long t_w0 = clock64();
 #endif
         const int nown = NT - NTW * wave;          // tiles this wave owns: wave-uniform
-        const int KB = (K + 15) >> 4;
+        const bool tail8 = (K & 15) == 8 && K > 16;
+        const int KB = tail8 ? K >> 4 : (K + 15) >> 4;
         if constexpr (NTW >= 2) {
-            if (nown >= 2) fwd_loop<2>(acc, W, NT, KB);
-            else if (nown == 1) fwd_loop<1>(acc, W, NT, KB);
+            if (nown >= 2) fwd_loop<2>(acc, W, NT, KB, tail8);
+            else if (nown == 1) fwd_loop<1>(acc, W, NT, KB, tail8);
         } else {
-            if (nown >= 1) fwd_loop<1>(acc, W, NT, KB);
+            if (nown >= 1) fwd_loop<1>(acc, W, NT, KB, tail8);
         }
 #ifdef RLC_STAMPS
         if (lane == 0 && stamp_buf) stamp_buf[48 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
@@ -392,8 +442,8 @@ struct Blk {
     // ---------------------------------------------------------------------------------------
     template <int NS, int NOWN, int BIT, bool TRICK>
     __device__ __forceinline__ void bwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NTk, const lds_f32* seed,
-                                             const lds_f32* wvec) {
-        const float* wp = W + (((size_t)(NTW * wave) * NTk) << 8) + (lane << 2);
+                                             const lds_f32* wvec, bool tail8, int NTblk) {
+        const float* wp = W + (((size_t)(NTW * wave) * NTblk) << 8) + (lane << 2);
         const lds_u8* mp = L.mask + c * MSTRIDE + 4 * g;
         const lds_f32* wvp = wvec + 4 * g;
         float sd[MT][NS];
@@ -407,7 +457,7 @@ struct Blk {
         auto loadB = [&](f32x4 (&dst)[NOWN], int ch) {
 #pragma unroll
             for (int i = 0; i < NOWN; i++)
-                dst[i] = *reinterpret_cast<const f32x4*>(wp + (((size_t)i * NTk + ch) << 8));
+                dst[i] = *reinterpret_cast<const f32x4*>(wp + (((size_t)i * NTblk + ch) << 8));
         };
         auto mac = [&](const f32x4 (&bin)[NOWN], int ch) {
             f32x4 wv[NS], b[NOWN];
@@ -442,13 +492,60 @@ struct Blk {
         };
         loadB(b0, 0);
         int ch = 0;
+        // one scheduling region per pair of chunks (see fwd_loop): next chunk's weight tile first, then per M tile
+        // its mask dword read ahead of the 4*NOWN MFMAs that consume the previous one
+        auto pin = [&]() {
+            __builtin_amdgcn_sched_group_barrier(0x020, NOWN, 0);              // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x100, NS + MT, 0);           // DS read: wvec rows + every mask dword
+        };
         for (; ch + 2 <= NTk; ch += 2) {
             loadB(b1, ch + 1);
             mac(b0, ch);
-            if (ch + 2 < NTk) loadB(b0, ch + 2);      // wave-uniform
+            pin();
+            loadB(b0, ch + 2 < NTk ? ch + 2 : NTk - 1);
             mac(b1, ch + 1);
+            pin();
         }
         if (ch < NTk) mac(b0, ch);
+        if (tail8) {
+            // row length = 16 NTk + 8: the last 8 n's in TWO steps -- lane group g takes n = 16 NTk + 2g + s: an 8-byte
+            // weight load (columns 2g, 2g+1 of the lane's row of the block), two mask bytes, two wvec entries per row
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const float* wt = W + (((size_t)(NTW * wave) * NTblk + NTk) << 8) + ((((g >> 1) << 4) + c) << 2) + 2 * (g & 1);
+            f32x2 bt[NOWN], wv[NS];
+#pragma unroll
+            for (int i = 0; i < NOWN; i++) bt[i] = *reinterpret_cast<const f32x2*>(wt + (((size_t)i * NTblk) << 8));
+#pragma unroll
+            for (int j = 0; j < NS; j++) wv[j] = *reinterpret_cast<const RLC_LDS f32x2*>(wvec + j * 256 + 16 * NTk + 2 * g);
+            if (TRICK) {
+#pragma unroll
+                for (int i = 0; i < NOWN; i++) bt[i] = bt[i] * wv[0];
+            }
+            f32x2 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                unsigned mw = *reinterpret_cast<const RLC_LDS unsigned short*>(L.mask + (16 * mt + c) * MSTRIDE + 16 * NTk + 2 * g);
+                if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x0101u;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    const float f = (float)((mw >> (8 * s2)) & 0xffu);
+                    if (TRICK) {
+                        av[mt][s2] = f;
+                    } else {
+                        float v = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < NS; j++) v += sd[mt][j] * wv[j][s2];
+                        av[mt][s2] = f * v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+        }
         if (TRICK) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
@@ -472,13 +569,15 @@ struct Blk {
                 for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const int nown = NT - NTW * wave;
-        const int NTk = (Nk + 15) >> 4;
+        const int NTblk = (Nk + 15) >> 4;          // blocks per row of the tile-blocked W
+        const bool tail8 = (Nk & 15) == 8 && Nk > 16;
+        const int NTk = tail8 ? Nk >> 4 : NTblk;
         constexpr bool TRICK = NS == 1 && !ACCUM;
         if constexpr (NTW >= 2) {
-            if (nown >= 2) bwd_loop<NS, 2, BIT, TRICK>(acc, W, NTk, seed, wvec);
-            else if (nown == 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec);
+            if (nown >= 2) bwd_loop<NS, 2, BIT, TRICK>(acc, W, NTk, seed, wvec, tail8, NTblk);
+            else if (nown == 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec, tail8, NTblk);
         } else {
-            if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec);
+            if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec, tail8, NTblk);
         }
     }
 
@@ -541,7 +640,7 @@ struct Blk {
                         if (q == s && !is_bias) gr = gw[q];
                     const int p = is_bias ? ob1 + k : oW1 + s * H1 + k;
                     float mm = m[p], vv = v[p];
-                    const float nv = adam_step(th[p], gr, mm, vv, alpha);
+                    const float nv = RLC_ADAM_SMALL(th[p], gr, mm, vv, alpha);
                     m[p] = mm; v[p] = vv; th[p] = nv;
                     if (tap) tap[p] = gr;
                     if (tt) tt[p] = polyak(tt[p], nv, tau);
@@ -617,21 +716,56 @@ struct Blk {
             }
             const lds_u8* mrow = L.mask + 16 * t + c;
             sub_begin();
-#pragma unroll 4
-            for (int ks = 0; ks < MT * 4; ks++) {
-                const int b = 4 * ks + gperm;
-                // D[b][n] for this lane's (b, n = 16t + c)
-                float dv = 0.0f;
+            // The batch is walked in MT groups of 4 k-steps (rows 16 gi + 4 j + gperm), fully unrolled, the operands
+            // of the next group in flight while the current group's 4*MCC MFMAs issue.  LDC: compile-time leading
+            // dimension of hbuf (every LDS address is then base + immediate), 0 = runtime.
+            struct Ops { float hf[4][MCC]; float sd[4][NS]; unsigned mk[4]; };
+            auto kloop = [&](auto ldc_tag) {
+                constexpr int LDC = decltype(ldc_tag)::value;
+                const int ld = LDC ? LDC : LDH;
+                const lds_f32* hq[MCC];
 #pragma unroll
-                for (int j = 0; j < NS; j++) dv += seed[b * NS + j] * wvn[j];
-                const float df = (mrow[b * MSTRIDE] & MBITS) ? dv : 0.0f;
-                // hbuf fragments, unmasked: columns kp >= H1 (last tile only) only feed rows that are never stored
-                float hf[MCC];
+                for (int q = 0; q < MCC; q++) hq[q] = L.hbuf + gperm * ld + kq[q];
+                const lds_f32* sp = seed + gperm * NS;
+                const lds_u8* mp = mrow + gperm * MSTRIDE;
+                auto load_ops = [&](Ops& o, int gi) {
 #pragma unroll
-                for (int q = 0; q < MCC; q++) hf[q] = L.hbuf[b * LDH + kq[q]];
+                    for (int j = 0; j < 4; j++) {
+                        const int row = 16 * gi + 4 * j;
 #pragma unroll
-                for (int q = 0; q < MCC; q++) acc[q] = mfma16(df, hf[q], acc[q]);
-            }
+                        for (int jj = 0; jj < NS; jj++) o.sd[j][jj] = sp[row * NS + jj];
+                        o.mk[j] = mp[row * MSTRIDE];
+#pragma unroll
+                        for (int q = 0; q < MCC; q++) o.hf[j][q] = hq[q][row * ld];
+                    }
+                };
+                auto mac_ops = [&](const Ops& o, int gi) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (gi == MT - 1 && j > 0 && 16 * gi + 4 * j >= B) continue;     // wave-uniform: all-zero seeds
+                        float dv = 0.0f;
+#pragma unroll
+                        for (int jj = 0; jj < NS; jj++) dv += o.sd[j][jj] * wvn[jj];
+                        const float df = (o.mk[j] & MBITS) ? dv : 0.0f;
+#pragma unroll
+                        for (int q = 0; q < MCC; q++) acc[q] = mfma16(df, o.hf[j][q], acc[q]);
+                    }
+                };
+                Ops o0, o1;
+                load_ops(o0, 0);
+#pragma unroll
+                for (int gi = 0; gi < MT; gi++) {
+                    if (gi + 1 < MT) load_ops((gi & 1) ? o0 : o1, gi + 1);
+                    mac_ops((gi & 1) ? o1 : o0, gi);
+                    if (gi + 1 < MT) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4 * (NS + 1 + MCC), 0);      // next group's reads first
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4 * MCC, 0);
+                    }
+                }
+            };
+            if (LDH == 200) kloop(std::integral_constant<int, 200>{});
+            else if (LDH == 136) kloop(std::integral_constant<int, 136>{});
+            else kloop(std::integral_constant<int, 0>{});
             sub_stamp(22);
             const bool n4ok = 16 * t + 4 * g < N;
 #pragma unroll
@@ -700,7 +834,7 @@ struct Blk {
                 float ge[NE];
 #pragma unroll
                 for (int j = 0; j < NE; j++) ge[j] = 0.0f;
-                for (int bb = 0; bb < MB / 4; bb++) {
+                for (int bb = 0; bb < MT * 4; bb++) {            // (forcing a full unroll here costs 1 %: registers)
                     const int b = 4 * bb + g;
                     float dv = 0.0f;
 #pragma unroll
@@ -715,7 +849,7 @@ struct Blk {
                     if (g == j && nok) {
                         const size_t p = rlc_blk_index(((H1 + 15) & ~15) + j, n, N);   // first extra block row + j
                         float mm = mp[p], vv = vp[p];
-                        const float nv = adam_step(Wp[p], gr, mm, vv, alpha);
+                        const float nv = RLC_ADAM_SMALL(Wp[p], gr, mm, vv, alpha);
                         mp[p] = mm; vp[p] = vv; Wp[p] = nv;
                         if (tapp) tapp[p] = gr;
                         Wt[p] = polyak(Wt[p], nv, tau);
