@@ -29,6 +29,7 @@ struct Smem {
     lds_i64* idx;
     lds_i32* pool;
     lds_i32* dups;
+    lds_f32x4* xbuf;    // hand-off of the split 13th tile (mfma_blocks.h)
 };
 
 // carve the dynamic LDS; base may be null (host: only the size is wanted)
@@ -61,6 +62,7 @@ __host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, lds_u8* b
     L.dq = (lds_f32*)take(sizeof(float) * MB);
     L.pool = (lds_i32*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     L.dups = (lds_i32*)take(sizeof(int) * 4);
+    L.xbuf = (lds_f32x4*)take(sizeof(float) * 4 * 64 * (MT - (MT + 3) / 4));
     if (out) *out = L;
     return off;
 }
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     u.S = d.S; u.H1 = d.H1; u.B = d.B; u.LDH = ldh_for(d.H1);
     Smem L;
     smem_carve(d, MT, (lds_u8*)smem, &L);
-    u.L.hbuf = L.hbuf; u.L.mask = L.mask;
+    u.L.hbuf = L.hbuf; u.L.mask = L.mask; u.L.xbuf = L.xbuf;
     const int tid = u.tid, S = d.S, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
     const int agent = first_agent + blockIdx.x;
 
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HC + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 const float w3 = (t < NT && n < HC) ? L.wvec[n] : 0.0f;
                 float s3 = 0.0f, s2 = 0.0f;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HC + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 if (t < NT && n < HC && u.g < 2) {
                     const int p = (u.g == 0) ? d.oWc3 + n : d.obc2 + n;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HA + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 const bool ok = t < NT && n < HA;
                 float w3[AD], s3[AD];
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const int NT = (HA + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 if (t < NT && n < HA && u.g <= AD) {
                     // lane group 0 -> ba2[n]; groups 1..AD -> Wa3[n][j]

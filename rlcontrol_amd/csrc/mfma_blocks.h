@@ -86,6 +86,7 @@ __host__ __device__ inline int ldh_for(int H1) {
 struct BlkLds {
     lds_f32* hbuf;
     lds_u8* mask;
+    lds_f32x4* xbuf;    // [MT - ceil(MT/4)][64] hand-off of a split tile's accumulators, or null: no tile is split
 };
 
 struct NoExtra {};
@@ -128,7 +129,29 @@ struct Blk {
     __device__ __forceinline__ void init_geometry() {
         tid = threadIdx.x; lane = tid & 63; wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         c = lane & 15; g = lane >> 4;
+        L.xbuf = nullptr;
     }
+
+    // ---------------------------------------------------------------------------------------
+    // N-tile ownership.  NTW = 1: wave w owns tile w.  NTW = 2: waves 0-3 own the adjacent tiles {2w, 2w+1}, waves 4-7
+    // (the SIMD partners of waves 0-3) own {8 + (w-4), 12 + (w-4)}: with 13 tiles (widths 196..208) the SIMDs carry
+    // 4/3/3/3 tiles instead of 4/4/3/2, and the ragged 13th tile is then SPLIT over the batch between waves 4-7 in
+    // the k-loops (fwd_gemm / bwd_gemm), so that every SIMD issues 3 tiles + 2 of 7 batch tiles; wave 4 collects the
+    // shares through L.xbuf and owns the tile in every epilogue.
+    // ---------------------------------------------------------------------------------------
+    __device__ __forceinline__ int tile0() const { return NTW == 1 ? wave : (wave < 4 ? 2 * wave : 4 + wave); }
+    __device__ __forceinline__ int tstep() const { return (NTW == 2 && wave >= 4) ? 4 : 1; }
+    __device__ __forceinline__ int tile_of(int i) const { return tile0() + i * tstep(); }
+    __device__ __forceinline__ int nown_of(int NT) const {
+        int n = 0;
+#pragma unroll
+        for (int i = 0; i < NTW; i++) n += tile_of(i) < NT ? 1 : 0;
+        return n;
+    }
+    static constexpr int MXS = (MT + 3) / 4;            // batch tiles of a split tile per wave (at most)
+    __device__ __forceinline__ bool split_mode(int NT) const { return NTW == 2 && NT == 13 && L.xbuf != nullptr; }
+    // batch-tile range [lo, hi) of wave 4+s's share of the split tile
+    __device__ __forceinline__ static int share_lo(int s) { return (s * MT + 3) / 4; }
 
     // ---------------------------------------------------------------------------------------
     // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
@@ -184,13 +207,39 @@ struct Blk {
     // loop unrolled by two, so there are no register-rotation moves either: per chunk a wave issues
     // MT ds_read_b128 + 4*NOWN global_load_dword + 4*MT*NOWN MFMAs and little else.
     // ---------------------------------------------------------------------------------------
-    template <int NOWN>
-    __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB, bool tail8) {
-        const float* wp = W + ((size_t)(NTW * wave) << 8) + (((((c >> 2) << 4) + 4 * g) << 2) + (c & 3));
+    // XTRA: besides its NOWN full tiles the wave computes batch tiles [xm0, xm0 + xnm) of the split tile xt into accx
+    template <int NOWN, bool XTRA>
+    __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB, bool tail8,
+                                             f32x4 (&accx)[MXS], int xt, int xm0) {
+        const int lofs = ((((c >> 2) << 4) + 4 * g) << 2) + (c & 3);
+        const float* wp = W + ((size_t)tile0() << 8) + lofs;
+        const int tst = tstep() << 8;
         const size_t wstep = (size_t)NT << 8;                       // floats between block rows
         const lds_f32* ap = L.hbuf + c * LDH + 4 * g;
         f32x4 a0[MT], a1[MT];
         float b0[NOWN][4], b1[NOWN][4];
+        // the split tile's share: its own A fragments (the batch tiles are a run-time range) and B fragment
+        const float* wpx = W + ((size_t)xt << 8) + lofs;
+        const lds_f32* apx = ap + 16 * xm0 * LDH;
+        f32x4 ax0[MXS], ax1[MXS];
+        float bx0[4], bx1[4];
+        auto loadX = [&](f32x4 (&da)[MXS], float (&db)[4], int ch) {
+            if (XTRA) {
+#pragma unroll
+                for (int m = 0; m < MXS; m++)      // a share shorter than MXS repeats its first tile (result unused)
+                    da[m] = *reinterpret_cast<const lds_f32x4*>(apx + 16 * (xm0 + m < MT ? m : 0) * LDH + 16 * ch);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++) db[s2] = wpx[(size_t)ch * wstep + 4 * s2];
+            }
+        };
+        auto macX = [&](const f32x4 (&da)[MXS], const float (&db)[4]) {
+            if (XTRA) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+                    for (int m = 0; m < MXS; m++) accx[m] = mfma16(da[m][s2], db[s2], accx[m]);
+            }
+        };
         auto loadA = [&](f32x4 (&dst)[MT], int ch) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const lds_f32x4*>(ap + 16 * mt * LDH + 16 * ch);
@@ -199,7 +248,7 @@ struct Blk {
 #pragma unroll
             for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                for (int s = 0; s < 4; s++) dst[i][s] = wp[(size_t)ch * wstep + (i << 8) + 4 * s];
+                for (int s = 0; s < 4; s++) dst[i][s] = wp[(size_t)ch * wstep + i * tst + 4 * s];
         };
         auto mac = [&](const f32x4 (&a)[MT], const float (&b)[NOWN][4]) {
 #pragma unroll
@@ -211,41 +260,51 @@ struct Blk {
         };
         loadB(b0, 0);
         loadA(a0, 0);
+        loadX(ax0, bx0, 0);
         int ch = 0;
         // Branch-free body (the prefetch index is clamped: an even chunk count re-reads its last chunk once) so that
         // both halves form ONE scheduling region, pinned by sched_group_barrier to: the 4*NOWN weight loads of the
         // next chunk first, then one A-fragment read per 4*NOWN MFMAs -- every load is issued a whole chunk
         // (4*MT*NOWN MFMAs) before its first use instead of wherever the scheduler sinks it.
         auto pin = [&]() {
-            __builtin_amdgcn_sched_group_barrier(0x020, 4 * NOWN, 0);          // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x020, 4 * NOWN + (XTRA ? 4 : 0), 0);      // VMEM read
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * NOWN, 0);      // MFMA
             }
+            if (XTRA) {
+                __builtin_amdgcn_sched_group_barrier(0x100, MXS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MXS, 0);
+            }
         };
         for (; ch + 2 <= KB; ch += 2) {
             loadB(b1, ch + 1);
             loadA(a1, ch + 1);
+            loadX(ax1, bx1, ch + 1);
             mac(a0, b0);
+            macX(ax0, bx0);
             pin();
             const int nx = ch + 2 < KB ? ch + 2 : KB - 1;
             loadB(b0, nx);
             loadA(a0, nx);
+            loadX(ax0, bx0, nx);
             mac(a1, b1);
+            macX(ax1, bx1);
             pin();
         }
-        if (ch < KB) mac(a0, b0);      // odd chunk count: the last chunk is already loaded
+        if (ch < KB) { mac(a0, b0); macX(ax0, bx0); }      // odd chunk count: the last chunk is already loaded
         if (tail8) {
             // K = 16 KB + 8: the last 8 k's in TWO steps instead of a zero-padded chunk of four -- lane group g takes
             // k = 16 KB + 2g + s (an 8-byte read of hbuf, two weight dwords per tile)
             const lds_f32* at = L.hbuf + c * LDH + 16 * KB + 2 * g;
-            const float* wt = W + ((size_t)(NTW * wave) << 8) + (size_t)KB * wstep + (((((c >> 2) << 4) + 2 * g) << 2) + (c & 3));
+            const int tofs = ((((c >> 2) << 4) + 2 * g) << 2) + (c & 3);
+            const float* wt = W + ((size_t)tile0() << 8) + (size_t)KB * wstep + tofs;
             float bt[NOWN][2];
 #pragma unroll
             for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) bt[i][s2] = wt[(i << 8) + 4 * s2];
+                for (int s2 = 0; s2 < 2; s2++) bt[i][s2] = wt[i * tst + 4 * s2];
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 av[MT];
 #pragma unroll
@@ -256,6 +315,39 @@ struct Blk {
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+            if (XTRA) {
+                const float* wtx = W + ((size_t)xt << 8) + (size_t)KB * wstep + tofs;
+#pragma unroll
+                for (int m = 0; m < MXS; m++) {
+                    const f32x2 avx = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * (xm0 + m < MT ? xm0 + m : xm0) * LDH);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) accx[m] = mfma16(avx[s2], wtx[4 * s2], accx[m]);
+                }
+            }
+        }
+    }
+
+    // wave 4 + s holds batch tiles [share_lo(s), share_lo(s+1)) of the split tile in accx: waves 5-7 pass theirs through
+    // L.xbuf, wave 4 assembles the whole tile in acc[.][1] (ACCUM: adds it)
+    template <bool ACCUM>
+    __device__ __forceinline__ void collect_split(f32x4 (&acc)[MT][NTW], const f32x4 (&accx)[MXS]) {
+        if constexpr (NTW >= 2) {
+            if (wave >= 5) {
+                const int lo = share_lo(wave - 4), hi = share_lo(wave - 3);
+#pragma unroll
+                for (int m = 0; m < MXS; m++)
+                    if (lo + m < hi) L.xbuf[(lo + m - MXS) * 64 + lane] = accx[m];
+            }
+            __syncthreads();
+            if (wave == 4) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    f32x4 v;
+                    if (mt < MXS) v = accx[mt < MXS ? mt : 0];
+                    else v = L.xbuf[(mt - MXS) * 64 + lane];
+                    acc[mt][1] = ACCUM ? acc[mt][1] + v : v;
+                }
+            }
         }
     }
 
@@ -268,14 +360,21 @@ struct Blk {
 #ifdef RLC_STAMPS
         const long long t_w0 = clock64();
 #endif
-        const int nown = NT - NTW * wave;          // tiles this wave owns: wave-uniform
+        const int nown = nown_of(NT);              // tiles this wave owns: wave-uniform
         const bool tail8 = (K & 15) == 8 && K > 16;
         const int KB = tail8 ? K >> 4 : (K + 15) >> 4;
+        f32x4 accx[MXS];
         if constexpr (NTW >= 2) {
-            if (nown >= 2) fwd_loop<2>(acc, W, NT, KB, tail8);
-            else if (nown == 1) fwd_loop<1>(acc, W, NT, KB, tail8);
+            if (split_mode(NT)) {                  // workgroup-uniform
+#pragma unroll
+                for (int m = 0; m < MXS; m++) accx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (wave >= 4) fwd_loop<1, true>(acc, W, NT, KB, tail8, accx, NT - 1, share_lo(wave - 4));
+                else fwd_loop<2, false>(acc, W, NT, KB, tail8, accx, 0, 0);
+                collect_split<false>(acc, accx);
+            } else if (nown >= 2) fwd_loop<2, false>(acc, W, NT, KB, tail8, accx, 0, 0);
+            else if (nown == 1) fwd_loop<1, false>(acc, W, NT, KB, tail8, accx, 0, 0);
         } else {
-            if (nown >= 1) fwd_loop<1>(acc, W, NT, KB, tail8);
+            if (nown >= 1) fwd_loop<1, false>(acc, W, NT, KB, tail8, accx, 0, 0);
         }
 #ifdef RLC_STAMPS
         if (lane == 0 && stamp_buf) stamp_buf[48 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
@@ -290,7 +389,7 @@ struct Blk {
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = tile_of(i);
             const int n = 16 * t + c;
             const bool ok = t < NT && n < N;
             const float bs = ok ? bias[n] : 0.0f;
@@ -320,7 +419,7 @@ struct Blk {
         float co[NTW][NJ];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = tile_of(i);
             const int n = 16 * t + c;
             const bool ok = t < NT && n < N;
 #pragma unroll
@@ -364,7 +463,7 @@ struct Blk {
         bool okk[NTW];
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = tile_of(i);
             const int n = 16 * t + c;
             const bool ok = t < NT && n < N;
             okk[i] = ok;
@@ -414,7 +513,7 @@ struct Blk {
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = tile_of(i);
             if (t < NT) {
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
@@ -440,10 +539,12 @@ struct Blk {
     // BIT < 0: the mask bytes are 0/1 as stored (single plane written with BIT 0 + OVERWRITE); BIT >= 0 selects a plane.
     // Same structure as fwd_loop: tiles owned is a template parameter, two register sets, no masks.
     // ---------------------------------------------------------------------------------------
-    template <int NS, int NOWN, int BIT, bool TRICK>
+    // XTRA: besides its NOWN full output tiles the wave computes batch tiles [xm0, ..) of the split output tile xt
+    template <int NS, int NOWN, int BIT, bool TRICK, bool XTRA>
     __device__ __forceinline__ void bwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NTk, const lds_f32* seed,
-                                             const lds_f32* wvec, bool tail8, int NTblk) {
-        const float* wp = W + (((size_t)(NTW * wave) * NTblk) << 8) + (lane << 2);
+                                             const lds_f32* wvec, bool tail8, int NTblk, f32x4 (&accx)[MXS], int xt, int xm0) {
+        const float* wp = W + (((size_t)tile0() * NTblk) << 8) + (lane << 2);
+        const size_t tst = ((size_t)tstep() * NTblk) << 8;
         const lds_u8* mp = L.mask + c * MSTRIDE + 4 * g;
         const lds_f32* wvp = wvec + 4 * g;
         float sd[MT][NS];
@@ -453,18 +554,32 @@ struct Blk {
 #pragma unroll
                 for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
         }
-        f32x4 b0[NOWN], b1[NOWN];
-        auto loadB = [&](f32x4 (&dst)[NOWN], int ch) {
+        // the split tile's share: its weight rows, and the mask / seed rows of its batch tiles (a run-time range)
+        const float* wpx = W + (((size_t)xt * NTblk) << 8) + (lane << 2);
+        int xrow[MXS];
+        float sdx[MXS][NS];
+        if (XTRA) {
+#pragma unroll
+            for (int m = 0; m < MXS; m++) {
+                xrow[m] = 16 * (xm0 + m < MT ? xm0 + m : xm0) + c;
+#pragma unroll
+                for (int j = 0; j < NS; j++) sdx[m][j] = seed[xrow[m] * NS + j];
+            }
+        }
+        f32x4 b0[NOWN], b1[NOWN], bx0, bx1;
+        auto loadB = [&](f32x4 (&dst)[NOWN], f32x4& dx, int ch) {
 #pragma unroll
             for (int i = 0; i < NOWN; i++)
-                dst[i] = *reinterpret_cast<const f32x4*>(wp + (((size_t)i * NTblk + ch) << 8));
+                dst[i] = *reinterpret_cast<const f32x4*>(wp + i * tst + ((size_t)ch << 8));
+            if (XTRA) dx = *reinterpret_cast<const f32x4*>(wpx + ((size_t)ch << 8));
         };
-        auto mac = [&](const f32x4 (&bin)[NOWN], int ch) {
-            f32x4 wv[NS], b[NOWN];
+        auto mac = [&](const f32x4 (&bin)[NOWN], const f32x4& binx, int ch) {
+            f32x4 wv[NS], b[NOWN], bx;
 #pragma unroll
             for (int j = 0; j < NS; j++) wv[j] = *reinterpret_cast<const lds_f32x4*>(wvp + j * 256 + 16 * ch);
 #pragma unroll
             for (int i = 0; i < NOWN; i++) b[i] = TRICK ? bin[i] * wv[0] : bin[i];
+            if (XTRA) bx = TRICK ? binx * wv[0] : binx;
             f32x4 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
@@ -489,32 +604,51 @@ struct Blk {
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], b[i][s], acc[mt][i]);
+            if (XTRA) {
+#pragma unroll
+                for (int m = 0; m < MXS; m++) {
+                    unsigned mw = *reinterpret_cast<const lds_u32*>(L.mask + xrow[m] * MSTRIDE + 4 * g + 16 * ch);
+                    if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x01010101u;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        float f = (float)((mw >> (8 * s)) & 0xffu);
+                        if (!TRICK) {
+                            float v = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < NS; j++) v += sdx[m][j] * wv[j][s];
+                            f *= v;
+                        }
+                        accx[m] = mfma16(f, bx[s], accx[m]);
+                    }
+                }
+            }
         };
-        loadB(b0, 0);
+        loadB(b0, bx0, 0);
         int ch = 0;
         // one scheduling region per pair of chunks (see fwd_loop): next chunk's weight tile first, then per M tile
         // its mask dword read ahead of the 4*NOWN MFMAs that consume the previous one
         auto pin = [&]() {
-            __builtin_amdgcn_sched_group_barrier(0x020, NOWN, 0);              // VMEM read
-            __builtin_amdgcn_sched_group_barrier(0x100, NS + MT, 0);           // DS read: wvec rows + every mask dword
+            __builtin_amdgcn_sched_group_barrier(0x020, NOWN + (XTRA ? 1 : 0), 0);              // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x100, NS + MT + (XTRA ? MXS : 0), 0);         // DS read: wvec rows + every mask dword
         };
         for (; ch + 2 <= NTk; ch += 2) {
-            loadB(b1, ch + 1);
-            mac(b0, ch);
+            loadB(b1, bx1, ch + 1);
+            mac(b0, bx0, ch);
             pin();
-            loadB(b0, ch + 2 < NTk ? ch + 2 : NTk - 1);
-            mac(b1, ch + 1);
+            loadB(b0, bx0, ch + 2 < NTk ? ch + 2 : NTk - 1);
+            mac(b1, bx1, ch + 1);
             pin();
         }
-        if (ch < NTk) mac(b0, ch);
+        if (ch < NTk) mac(b0, bx0, ch);
         if (tail8) {
             // row length = 16 NTk + 8: the last 8 n's in TWO steps -- lane group g takes n = 16 NTk + 2g + s: an 8-byte
             // weight load (columns 2g, 2g+1 of the lane's row of the block), two mask bytes, two wvec entries per row
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const float* wt = W + (((size_t)(NTW * wave) * NTblk + NTk) << 8) + ((((g >> 1) << 4) + c) << 2) + 2 * (g & 1);
+            const int tofs = ((((g >> 1) << 4) + c) << 2) + 2 * (g & 1);
+            const float* wt = W + (((size_t)tile0() * NTblk + NTk) << 8) + tofs;
             f32x2 bt[NOWN], wv[NS];
 #pragma unroll
-            for (int i = 0; i < NOWN; i++) bt[i] = *reinterpret_cast<const f32x2*>(wt + (((size_t)i * NTblk) << 8));
+            for (int i = 0; i < NOWN; i++) bt[i] = *reinterpret_cast<const f32x2*>(wt + i * tst);
 #pragma unroll
             for (int j = 0; j < NS; j++) wv[j] = *reinterpret_cast<const RLC_LDS f32x2*>(wvec + j * 256 + 16 * NTk + 2 * g);
             if (TRICK) {
@@ -545,6 +679,26 @@ struct Blk {
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+            if (XTRA) {
+                f32x2 btx = *reinterpret_cast<const f32x2*>(W + (((size_t)xt * NTblk + NTk) << 8) + tofs);
+                if (TRICK) btx = btx * wv[0];
+#pragma unroll
+                for (int m = 0; m < MXS; m++) {
+                    unsigned mw = *reinterpret_cast<const RLC_LDS unsigned short*>(L.mask + xrow[m] * MSTRIDE + 16 * NTk + 2 * g);
+                    if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x0101u;
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        float f = (float)((mw >> (8 * s2)) & 0xffu);
+                        if (!TRICK) {
+                            float v = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < NS; j++) v += sdx[m][j] * wv[j][s2];
+                            f *= v;
+                        }
+                        accx[m] = mfma16(f, btx[s2], accx[m]);
+                    }
+                }
+            }
         }
         if (TRICK) {
 #pragma unroll
@@ -552,6 +706,11 @@ struct Blk {
                 const f32x4 sv = *reinterpret_cast<const lds_f32x4*>(&seed[16 * mt + 4 * g]);
 #pragma unroll
                 for (int i = 0; i < NOWN; i++) acc[mt][i] = acc[mt][i] * sv;
+            }
+            if (XTRA) {
+#pragma unroll
+                for (int m = 0; m < MXS; m++)
+                    accx[m] = accx[m] * *reinterpret_cast<const lds_f32x4*>(&seed[16 * (xm0 + m < MT ? xm0 + m : xm0) + 4 * g]);
             }
         }
     }
@@ -568,16 +727,23 @@ struct Blk {
 #pragma unroll
                 for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const int nown = NT - NTW * wave;
+        const int nown = nown_of(NT);
         const int NTblk = (Nk + 15) >> 4;          // blocks per row of the tile-blocked W
         const bool tail8 = (Nk & 15) == 8 && Nk > 16;
         const int NTk = tail8 ? Nk >> 4 : NTblk;
         constexpr bool TRICK = NS == 1 && !ACCUM;
+        f32x4 accx[MXS];
         if constexpr (NTW >= 2) {
-            if (nown >= 2) bwd_loop<NS, 2, BIT, TRICK>(acc, W, NTk, seed, wvec, tail8, NTblk);
-            else if (nown == 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec, tail8, NTblk);
+            if (split_mode(NT)) {                  // workgroup-uniform
+#pragma unroll
+                for (int m = 0; m < MXS; m++) accx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (wave >= 4) bwd_loop<NS, 1, BIT, TRICK, true>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, NT - 1, share_lo(wave - 4));
+                else bwd_loop<NS, 2, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
+                collect_split<ACCUM>(acc, accx);
+            } else if (nown >= 2) bwd_loop<NS, 2, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
+            else if (nown == 1) bwd_loop<NS, 1, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
         } else {
-            if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK>(acc, W, NTk, seed, wvec, tail8, NTblk);
+            if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
         }
     }
 
@@ -598,7 +764,7 @@ struct Blk {
         const int NT = (H1 + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
-            const int t = NTW * wave + i;
+            const int t = tile_of(i);
             if (t >= NT) continue;
             const int k = 16 * t + c;
             float gb = 0.0f;

@@ -41,6 +41,7 @@ struct NSmem {
     lds_i32* pool;
     lds_i32* dups;
     lds_f32* pol;        // scratch of the on-device training step (naf_rollout_device.h)
+    lds_f32x4* xbuf;     // hand-off of the split 13th tile (mfma_blocks.h)
 };
 
 template <int MSTRIDE>
@@ -73,6 +74,7 @@ __host__ __device__ inline size_t nsmem_carve(const RlcNafDims& d, int MT, lds_u
     L.pool = (lds_i32*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     L.dups = (lds_i32*)take(sizeof(int) * 4);
     L.pol = (lds_f32*)take(sizeof(float) * (naf_policy_lds_floats(d) + 4));
+    L.xbuf = (lds_f32x4*)take(sizeof(float) * 4 * 64 * (MT - (MT + 3) / 4));
     if (out) *out = L;
     return off;
 }
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
     u.S = d.S; u.H1 = d.L1; u.B = d.B; u.LDH = ldh_for(d.L1);
     NSmem L;
     nsmem_carve<MSTRIDE>(d, MT, (lds_u8*)smem, &L);
-    u.L.hbuf = L.hbuf; u.L.mask = L.mask;
+    u.L.hbuf = L.hbuf; u.L.mask = L.mask; u.L.xbuf = L.xbuf;
     const int tid = u.tid, S = d.S, L1 = d.L1, L2 = d.L2, B = d.B, LDH = u.LDH;
     const int agent = first_agent + blockIdx.x;
 
@@ -223,6 +225,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         u.template bias_relu<0>(acca, th + d.ba2, L2);
         u.template row_dot<false, AD>(acca, L2, [&](int n, int j) { return L.wvec[j * 256 + n]; }, L.part_a);
         u.template store_masks<0, true>(acca, L2);
+        if (u.split_mode((L2 + 15) >> 4)) __syncthreads();      // the split tile's hand-off buffer is reused
         u.fwd_gemm(acc, th + d.Wv2, L2, L1);
         u.template bias_relu<0>(acc, th + d.bv2, L2);
         u.template row_dot<false, 1>(acc, L2, [&](int n, int) { return wv3[n]; }, L.part_v);
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             const int NT = (L2 + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 const bool ok = t < NT && n < L2;
                 float w3[AD], s3[AD];
@@ -320,6 +323,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         // ================= 5: d trunk = V branch (rank one) + mu branch (accumulated) + heads =================
         const float alpha = adam_alpha(dv.lr[agent], pw[0], pw[1]);
         u.template bwd_gemm<1, 1, false>(acc, th + d.Wv2, L2, L1, L.dV, wv3);
+        if (u.split_mode((L1 + 15) >> 4)) __syncthreads();      // the split tile's hand-off buffer is reused
         u.template bwd_gemm<AD, 0, true>(acc, th + d.Wa2, L2, L1, L.dz, L.wvec);
         __syncthreads();
         u.trunk_grad_adam(acc, th, mm, vv, alpha, d.W1, d.b1, tapg, tt, tau, L.x, [&](int b, int k) {
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             const int NT = (L2 + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 if (t < NT && n < L2) {
                     // targets: 0 ba2[n], 1..A Wa3[n][j], A+1 Wv3[n], A+2 bv2[n]

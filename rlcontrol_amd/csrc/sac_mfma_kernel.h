@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             const int NT = (L2C + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 const float w3 = (t < NT && n < L2C) ? th[d.qW3 + n] : 0.0f;
                 float s3 = 0.0f, s2 = 0.0f;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             const int NT = (L2A + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 const bool ok = t < NT && n < L2A;
                 float w3[NS], s3[NS];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             const int NT = (L2A + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 if (t < NT && n < L2A) {
                     // lane group 0 -> pb2[n]; targets 1..A -> Wm[n][j]; A+1..2A -> Ws[n][j]
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             const int NT = (L2C + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 if (t < NT && n < L2C && u.g < 2)
                     U::adam_scalar(th, mm, vv, tt, tapg, u.g == 0 ? d.qW3 + n : d.qb2 + n, u.g == 0 ? g_qw3[i] : g_qb2[i],
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             const int NT = (L2C + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 const float w3 = (t < NT && n < L2C) ? L.wvec[n] : 0.0f;
                 float s3 = 0.0f, s2 = 0.0f;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             const int NT = (L2C + 15) >> 4;
 #pragma unroll
             for (int i = 0; i < NTW; i++) {
-                const int t = NTW * u.wave + i;
+                const int t = u.tile_of(i);
                 const int n = 16 * t + u.c;
                 if (t < NT && n < L2C && u.g < 2)
                     U::adam_scalar(th, mm, vv, tt, tapg, u.g == 0 ? d.vW3 + n : d.vb2 + n, u.g == 0 ? g_vw3[i] : g_vb2[i],
