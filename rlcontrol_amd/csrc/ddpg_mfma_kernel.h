@@ -250,12 +250,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                 g_bc2[i] = col4_sum(s2);
             }
         }
-        u.template store_masks<0, true>(acc, HC);
+        u.template store_masks<-2, true>(acc, HC);
         __syncthreads();
         STAMP();
         // dh1 = (dg2 . Wc2[:H1]^T) * relu'(h1) -> W1/b1 gradients -> critic Adam on the trunk (Q1)
         const float alpha_c = adam_alpha(lr_c, pw[2], pw[3]);
-        u.template bwd_gemm<1>(acc, th + d.oWc2, HC, H1, L.dq, L.wvec);
+        u.template bwd_gemm<1, -2>(acc, th + d.oWc2, HC, H1, L.dq, L.wvec);
         __syncthreads();      // every wave has finished reading the pre-step Wc2 rows and W1
         STAMP();
         u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f, L.x);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         u.fwd_gemm(acc, th + d.oWa2, HA, H1);
         u.template bias_relu<0>(acc, th + d.oba2, HA);
         u.template row_dot<false, AD>(acc, HA, [&](int n, int j) { return th[d.oWa3 + n * AD + j]; }, L.part);   // z partials
-        u.template store_masks<0, true>(acc, HA);
+        u.template store_masks<-2, true>(acc, HA);
         __syncthreads();
         STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             }
         }
         const float alpha_a = adam_alpha(lr_a, pw[0], pw[1]);
-        u.template bwd_gemm<AD>(acc, th + d.oWa2, HA, H1, L.dz, L.wvec);
+        u.template bwd_gemm<AD, -2>(acc, th + d.oWa2, HA, H1, L.dz, L.wvec);
         __syncthreads();
         STAMP();
         u.trunk_grad_adam(acc, th, m_a, v_a, alpha_a, d.oW1, d.ob1, tap_ga, tt, tau, L.x);

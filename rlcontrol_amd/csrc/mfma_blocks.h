@@ -507,7 +507,8 @@ struct Blk {
 
     // relu masks of the accumulators -> bit plane BIT of one byte per (row, unit).  OVERWRITE: the byte becomes
     // the mask of this plane alone (other planes cleared); otherwise the plane is OR-ed in (the same thread owns
-    // the same byte for every plane: no race).
+    // the same byte for every plane: no race).  BIT == -2 (single plane, OVERWRITE): the byte is 0x38 = 1.0 in OCP
+    // fp8 e4m3, which the backward GEMM turns into floats two at a time (v_cvt_pk_f32_fp8).
     template <int BIT, bool OVERWRITE>
     __device__ __forceinline__ void store_masks(const f32x4 (&acc)[MT][NTW], int N) {
         const int NT = (N + 15) >> 4;
@@ -520,11 +521,25 @@ struct Blk {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         lds_u8* p = &L.mask[(16 * mt + 4 * g + r) * MSTRIDE + 16 * t + c];
-                        const unsigned char bit = acc[mt][i][r] > 0.0f ? (unsigned char)(1u << BIT) : (unsigned char)0;
+                        const unsigned char bit = acc[mt][i][r] > 0.0f ? (unsigned char)(BIT == -2 ? 0x38u : 1u << (BIT < 0 ? 0 : BIT)) : (unsigned char)0;
                         if (OVERWRITE) *p = bit;
-                        else *p = (unsigned char)((*p & ~(1u << BIT)) | bit);
+                        else *p = (unsigned char)((*p & ~(1u << (BIT < 0 ? 0 : BIT))) | bit);
                     }
             }
+        }
+    }
+
+    // four mask bytes -> four floats (0.0 / 1.0).  BIT == -2: fp8-coded bytes, two per v_cvt_pk_f32_fp8; otherwise 0/1
+    // bytes through v_cvt_f32_ubyte<s>
+    template <int BITV>
+    __device__ __forceinline__ static void mask4(unsigned mw, float (&f)[4], std::integral_constant<int, BITV>) {
+        if constexpr (BITV == -2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)mw, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)mw, true);
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) f[s] = (float)((mw >> (8 * s)) & 0xffu);
         }
     }
 
@@ -585,9 +600,11 @@ struct Blk {
             for (int mt = 0; mt < MT; mt++) {
                 unsigned mw = *reinterpret_cast<const lds_u32*>(mp + 16 * mt * MSTRIDE + 16 * ch);
                 if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x01010101u;
+                float mf[4];
+                mask4(mw, mf, std::integral_constant<int, BIT>{});
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    const float f = (float)((mw >> (8 * s)) & 0xffu);        // v_cvt_f32_ubyte<s>: 0.0 or 1.0
+                    const float f = mf[s];                                   // 0.0 or 1.0
                     if (TRICK) {
                         av[mt][s] = f;
                     } else {
@@ -609,9 +626,11 @@ struct Blk {
                 for (int m = 0; m < MXS; m++) {
                     unsigned mw = *reinterpret_cast<const lds_u32*>(L.mask + xrow[m] * MSTRIDE + 4 * g + 16 * ch);
                     if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x01010101u;
+                    float mf[4];
+                    mask4(mw, mf, std::integral_constant<int, BIT>{});
 #pragma unroll
                     for (int s = 0; s < 4; s++) {
-                        float f = (float)((mw >> (8 * s)) & 0xffu);
+                        float f = mf[s];
                         if (!TRICK) {
                             float v = 0.0f;
 #pragma unroll
@@ -660,9 +679,11 @@ struct Blk {
             for (int mt = 0; mt < MT; mt++) {
                 unsigned mw = *reinterpret_cast<const RLC_LDS unsigned short*>(L.mask + (16 * mt + c) * MSTRIDE + 16 * NTk + 2 * g);
                 if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x0101u;
+                float mf[4];
+                mask4(mw, mf, std::integral_constant<int, BIT>{});
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
-                    const float f = (float)((mw >> (8 * s2)) & 0xffu);
+                    const float f = mf[s2];
                     if (TRICK) {
                         av[mt][s2] = f;
                     } else {
@@ -686,9 +707,11 @@ struct Blk {
                 for (int m = 0; m < MXS; m++) {
                     unsigned mw = *reinterpret_cast<const RLC_LDS unsigned short*>(L.mask + xrow[m] * MSTRIDE + 16 * NTk + 2 * g);
                     if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x0101u;
+                    float mf[4];
+                    mask4(mw, mf, std::integral_constant<int, BIT>{});
 #pragma unroll
                     for (int s2 = 0; s2 < 2; s2++) {
-                        float f = (float)((mw >> (8 * s2)) & 0xffu);
+                        float f = mf[s2];
                         if (!TRICK) {
                             float v = 0.0f;
 #pragma unroll
@@ -733,6 +756,9 @@ struct Blk {
         const int NTk = tail8 ? Nk >> 4 : NTblk;
         constexpr bool TRICK = NS == 1 && !ACCUM;
         f32x4 accx[MXS];
+#ifdef RLC_STAMPS
+        const long long t_w0 = clock64();
+#endif
         if constexpr (NTW >= 2) {
             if (split_mode(NT)) {                  // workgroup-uniform
 #pragma unroll
@@ -745,6 +771,9 @@ struct Blk {
         } else {
             if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
         }
+#ifdef RLC_STAMPS
+        if (lane == 0 && stamp_buf) stamp_buf[56 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
+#endif
     }
 
     // epilogue of bwd_gemm: dh1 = (acc [+ extra(b, k)]) * (hbuf > 0); column-reduce into the W1 / b1 gradients of

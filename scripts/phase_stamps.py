@@ -49,6 +49,8 @@ def main():
         print("  %-24s %9.0f cyc  %5.1f %%" % (n, c, 100 * c / tot.sum()))
     pw = pop.last_tap(0, "grads_c")[48:56] / U / 5
     print("  forward-GEMM k-loop cycles per wave (mean of the 5 GEMMs): " + " ".join("%.0f" % v for v in pw))
+    pb = pop.last_tap(0, "grads_c")[56:64] / U / 2
+    print("  backward-GEMM k-loop cycles per wave (mean of the 2 GEMMs): " + " ".join("%.0f" % v for v in pb))
     sg = pop.last_tap(0, "grads_c")[25:28] / U
     print("  thread 0 inside sample+gather: ring/counter loads %.0f, sampler %.0f, gather %.0f" % tuple(sg))
     sub = pop.last_tap(0, "grads_c")[21:25] / U
