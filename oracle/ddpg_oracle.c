@@ -32,6 +32,7 @@
  * The critic's concat puts the action LAST (hydra_ddpg_network.py:128), so rows H1..H1+A-1 of Wc2
  * multiply the action.
  */
+#include "ftz.h"
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -164,7 +165,7 @@ void ddpg_oracle_qval(int S, int A, int H1, int HA, int HC, const float* theta, 
  *   taps (may be NULL): q_pre[B] critic output before its step (train_critic's first fetch),
  *                       y[B] TD target, a_out[B,A] scaled actor output, dqda[B,A], grads_c[P], grads_a[P]
  */
-void ddpg_oracle_update(int S, int A, int H1, int HA, int HC, int B,
+static void ddpg_oracle_update_impl(int S, int A, int H1, int HA, int HC, int B,
                         float* theta, float* theta_t, float* m_a, float* v_a, float* m_c, float* v_c, float* pw,
                         const float* s, const float* a, const double* r, const float* s2, const double* gam,
                         float actor_lr, float critic_lr, float tau,
@@ -293,4 +294,16 @@ void ddpg_oracle_update(int S, int A, int H1, int HA, int HC, int B,
 
     free(x); free(x2); free(h1); free(h2); free(g2); free(mu); free(aout); free(q); free(y); free(dq);
     free(dg2); free(dh2); free(dh1); free(dqda); free(dz); free(g);
+}
+
+void ddpg_oracle_update(int S, int A, int H1, int HA, int HC, int B,
+                        float* theta, float* theta_t, float* m_a, float* v_a, float* m_c, float* v_c, float* pw,
+                        const float* s, const float* a, const double* r, const float* s2, const double* gam,
+                        float actor_lr, float critic_lr, float tau,
+                        int do_clip, const float* smin, const float* smax, const float* amax,
+                        float* tap_q, float* tap_y, float* tap_aout, float* tap_dqda,
+                        float* tap_gc, float* tap_ga) {
+    const unsigned csr = oracle_ftz_on();       /* TF-1.15 CPU arithmetic: denormals flushed (oracle/ftz.h) */
+    ddpg_oracle_update_impl(S, A, H1, HA, HC, B, theta, theta_t, m_a, v_a, m_c, v_c, pw, s, a, r, s2, gam, actor_lr, critic_lr, tau, do_clip, smin, smax, amax, tap_q, tap_y, tap_aout, tap_dqda, tap_gc, tap_ga);
+    oracle_ftz_restore(csr);
 }

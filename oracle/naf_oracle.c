@@ -15,6 +15,7 @@
  * tf.clip_by_value passes the gradient where lo <= x <= hi.  TensorFlow 1.15 arithmetic: "parity unpinned";
  * cross-checked by tests/torch_ref_naf.py.
  */
+#include "ftz.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -143,7 +144,7 @@ void naf_oracle_act(int S, int A, int L1, int L2, const float* theta, const floa
  * One update_network (agents/NAF.py:69-75).  theta, theta_t, m, v [P]; pw[2] = {b1^t, b2^t};
  * s,a,s2 fp32 [B,*]; r, gam float64 [B].  taps (may be NULL): q[B], y[B], V[B], grads[P]
  */
-void naf_oracle_update(int S, int A, int L1, int L2, int B, float* theta, float* theta_t, float* m, float* v, float* pw,
+static void naf_oracle_update_impl(int S, int A, int L1, int L2, int B, float* theta, float* theta_t, float* m, float* v, float* pw,
                        const float* s, const float* a, const double* r, const float* s2, const double* gam, float lr,
                        float tau, int do_clip, const float* smin, const float* smax, const float* amax, float* tap_q,
                        float* tap_y, float* tap_V, float* tap_g) {
@@ -251,4 +252,13 @@ void naf_oracle_update(int S, int A, int L1, int L2, int B, float* theta, float*
     for (int i = 0; i < P; i++) theta_t[i] += tau * (theta[i] - theta_t[i]);
     free(xc); free(x2c); free(h1); free(ha); free(hv); free(mt); free(V); free(dpre); free(npre); free(y); free(q);
     free(dz); free(dd); free(dn); free(dV); free(dha); free(dhv); free(dh1); free(g);
+}
+
+void naf_oracle_update(int S, int A, int L1, int L2, int B, float* theta, float* theta_t, float* m, float* v, float* pw,
+                       const float* s, const float* a, const double* r, const float* s2, const double* gam, float lr,
+                       float tau, int do_clip, const float* smin, const float* smax, const float* amax, float* tap_q,
+                       float* tap_y, float* tap_V, float* tap_g) {
+    const unsigned csr = oracle_ftz_on();       /* TF-1.15 CPU arithmetic: denormals flushed (oracle/ftz.h) */
+    naf_oracle_update_impl(S, A, L1, L2, B, theta, theta_t, m, v, pw, s, a, r, s2, gam, lr, tau, do_clip, smin, smax, amax, tap_q, tap_y, tap_V, tap_g);
+    oracle_ftz_restore(csr);
 }

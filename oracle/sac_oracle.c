@@ -23,6 +23,7 @@
  * Parameter blob (variable creation order under 'main'): pi: W1[S,L1a] b1 W2[L1a,L2a] b2 Wm[L2a,A] bm Ws[L2a,A] bs |
  *   qf: W1[S,L1c] b1 W2[L1c+A,L2c] b2 W3[L2c] b3 | vf: W1[S,L1c] b1 W2[L1c,L2c] b2 W3[L2c] b3
  */
+#include "ftz.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -153,7 +154,7 @@ void sac_oracle_act(int S, int A, int L1A, int L2A, int L1C, int L2C, const floa
  *   pw[4] = {pi b1^t, pi b2^t, value b1^t, value b2^t};  r, gam fp32 (placeholders are fp32 here)
  *   taps (may be NULL): q[B], v[B], logp[B], q_pi[B], losses[3] = {pi_loss, q_loss, v_loss}, grads[P]
  */
-void sac_oracle_update(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, float* theta, float* theta_t, float* m,
+static void sac_oracle_update_impl(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, float* theta, float* theta_t, float* m,
                        float* v, float* pw, const float* s, const float* a, const float* r, const float* s2,
                        const float* gam, const float* eps, float pi_lr, float qv_lr, float alpha_ent, float tau,
                        int do_clip, float smin0, float smax0, float amax0, float* tap_q, float* tap_v,
@@ -325,4 +326,14 @@ void sac_oracle_update(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, 
     free(xc); free(x2c); free(ph1); free(ph2); free(mu); free(lsp); free(t_); free(std_); free(pit); free(api);
     free(logp); free(qh1); free(qh2); free(qh2p); free(q); free(qpi); free(vh1); free(vh2); free(vv); free(th1);
     free(th2); free(vt); free(g); free(d1); free(d0); free(dmu); free(dls); free(dout);
+}
+
+void sac_oracle_update(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, float* theta, float* theta_t, float* m,
+                       float* v, float* pw, const float* s, const float* a, const float* r, const float* s2,
+                       const float* gam, const float* eps, float pi_lr, float qv_lr, float alpha_ent, float tau,
+                       int do_clip, float smin0, float smax0, float amax0, float* tap_q, float* tap_v,
+                       float* tap_logp, float* tap_qpi, float* tap_loss, float* tap_g) {
+    const unsigned csr = oracle_ftz_on();       /* TF-1.15 CPU arithmetic: denormals flushed (oracle/ftz.h) */
+    sac_oracle_update_impl(S, A, L1A, L2A, L1C, L2C, B, theta, theta_t, m, v, pw, s, a, r, s2, gam, eps, pi_lr, qv_lr, alpha_ent, tau, do_clip, smin0, smax0, amax0, tap_q, tap_v, tap_logp, tap_qpi, tap_loss, tap_g);
+    oracle_ftz_restore(csr);
 }

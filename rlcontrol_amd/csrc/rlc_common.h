@@ -353,7 +353,11 @@ __device__ __forceinline__ float clip_state_val(float v, int do_clip, float lo, 
 }
 
 // TF-1.15 ApplyAdam on one element (core/kernels/training_ops.cc, non-Nesterov; quirk Q2)
+// Every product and sum is rounded (and, with denormals flushed, flushed) on its own, as in TF's Eigen expression
+// m += (g - m) * (1 - beta1): contracted into an fma the decrement of an idle slot would never flush and m would decay
+// to zero, whereas the reference's checkpoints show idle slots resting at 9..10 x FLT_MIN (tests/test_ckpt_pins.py).
 __device__ __forceinline__ float adam_step(float var, float g, float& m, float& v, float alpha) {
+#pragma clang fp contract(off)
     m += (g - m) * (1.0f - 0.9f);
     v += (g * g - v) * (1.0f - 0.999f);
     return var - (m * alpha) / (sqrtf(v) + 1e-8f);
@@ -362,6 +366,7 @@ __device__ __forceinline__ float adam_step(float var, float g, float& m, float& 
 // same update with the hardware sqrt / reciprocal (1 ulp each) instead of the IEEE-exact expansions:
 // ~10 VALU instead of ~30 per element; relative deviation ~2e-7, far inside the 1e-5 parity bar
 __device__ __forceinline__ float adam_step_fast(float var, float g, float& m, float& v, float alpha) {
+#pragma clang fp contract(off)
     m += (g - m) * (1.0f - 0.9f);
     v += (g * g - v) * (1.0f - 0.999f);
     return var - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + 1e-8f);

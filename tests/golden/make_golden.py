@@ -209,6 +209,41 @@ def bimodal_ckpt():
     return out
 
 
+# reward functions of the five Bimodal1D environments the checkpoints were fitted to: (maximum 1, maximum 2, height 1,
+# height 2, stddev 1, stddev 2), restated from environments/environments.py (eq_var1 :573-587, eq_var2 :660-673,
+# eq_var3 :747-760, uneq_var1 :312-325, uneq_var2 :399-412); reward(a) = h1 exp(-.5((a-m1)/s1)^2) + h2 exp(-.5((a-m2)/s2)^2)
+BIMODAL_REWARDS = {
+    "eq_var1": (-0.6, 0.6, 1.0, 1.0, 0.2, 0.2),
+    "eq_var2": (-0.8, 0.8, 1.0, 1.0, 0.2, 0.2),
+    "eq_var3": (-1.0, 1.0, 1.0, 1.0, 0.2, 0.2),
+    "uneq_var1": (-1.0, 1.0, 1.0, 1.5, 0.4, 0.2),
+    "uneq_var2": (-1.0, 1.0, 1.0, 1.5, 0.3, 0.1),
+}
+CKPT_SHAPES = [("b1", (200,)), ("W1", (1, 200)), ("b2", (200,)), ("W2", (201, 200)), ("b3", (1,)), ("W3", (200, 1))]
+
+
+def bimodal_ckpts_all():
+    """Every Bimodal1DEnv_trueQ_ckpt/*.data file (SAC main/qf, 10 000 Adam steps at batch 32): weights of all five,
+    the optimizer's beta powers, and the Adam slots m / v in full (they pin the value | Adam | Adam_1 slot order and the
+    [in, out] / action-as-last-row layout through their exact-zero pattern).  Weights-only parse of raw fp32."""
+    out = {}
+    for name, rew in BIMODAL_REWARDS.items():
+        d = np.fromfile(os.path.join(REF, "Bimodal1DEnv_trueQ_ckpt",
+                                     "Bimodal1DEnv_%s_trueQ_learned.data-00000-of-00001" % name), dtype="<f4")
+        assert d.size == 123005
+        out[name + "/beta_powers"] = d[:2].copy()
+        out[name + "/reward"] = np.asarray(rew, np.float64)
+        pos = 2
+        for tn, shp in CKPT_SHAPES:
+            n = int(np.prod(shp))
+            out["%s/%s" % (name, tn)] = d[pos:pos + n].reshape(shp).copy()
+            out["%s/%s_m" % (name, tn)] = d[pos + n:pos + 2 * n].reshape(shp).copy()
+            out["%s/%s_v" % (name, tn)] = d[pos + 2 * n:pos + 3 * n].reshape(shp).copy()
+            pos += 3 * n
+        assert pos == d.size
+    return out
+
+
 def main():
     with open(os.path.join(HERE, "sweep_params.json"), "w") as f:
         json.dump(sweep_vectors(), f, indent=1)
@@ -226,6 +261,7 @@ def main():
         json.dump(rms_state(), f, indent=1)
     ck = bimodal_ckpt()
     np.savez_compressed(os.path.join(HERE, "bimodal_uneq_var1_qf.npz"), **ck)
+    np.savez_compressed(os.path.join(HERE, "bimodal_qf_ckpts.npz"), **bimodal_ckpts_all())
     print("golden vectors written to", HERE)
 
 
