@@ -265,21 +265,33 @@ def main_distributed(args, agent_json, env_json, train_env, test_env, env_params
     mine = sweep.rank_indices(args.indices[0], args.indices[1], args.indices[2], rank, world)
     local = new_data_dict(agent_json, env_json)
     verbose = (not args.quiet) and rank == 0
-    if args.device_rollout:
-        if mine:
-            run_indices_on_device(mine, agent_json, env_json, env_params, arg_params, local, verbose=verbose)
-    else:
-        for index in mine:
-            run_index(index, agent_json, env_json, train_env, test_env, env_params, arg_params, local, verbose=verbose)
-    # local runs in index order (each setting's list is in increasing index = increasing seed)
     n_settings = get_sweep_parameters(agent_json['sweeps'], 0)[1]
-    runs = {}
-    for sweep_id, sd in local["experiment_data"].items():
-        for rd in sd["runs"]:
-            runs[rd["random_seed"] * n_settings + sweep_id] = rd
     total = int(env_json["TotalMilSteps"] * 1000000)
     interval = int(env_json["EvalIntervalMilSteps"] * 1000000)
     eval_shape = (total // interval + 1, int(env_json["EvalEpisodes"]))
+    runs, failure = {}, None
+    try:
+        if args.device_rollout:
+            if mine:
+                run_indices_on_device(mine, agent_json, env_json, env_params, arg_params, local, verbose=verbose)
+        else:
+            for index in mine:
+                run_index(index, agent_json, env_json, train_env, test_env, env_params, arg_params, local, verbose=verbose)
+        # local runs in index order (each setting's list is in increasing index = increasing seed)
+        for sweep_id, sd in local["experiment_data"].items():
+            for rd in sd["runs"]:
+                runs[rd["random_seed"] * n_settings + sweep_id] = rd
+                if np.asarray(rd["eval_episode_rewards"]).size > eval_shape[0] * eval_shape[1]:
+                    raise ValueError("run %d holds more evaluations than the exchange record" % rd["random_seed"])
+    except Exception as e:           # a failing rank still reaches the collectives below, carrying an error flag:
+        failure = e                  # the other ranks must not sit in the all-gather until torchrun tears the job down
+        import traceback
+        traceback.print_exc()
+    if sweep.all_reduce_max(1 if failure is not None else 0, device):
+        dist.barrier()
+        dist.destroy_process_group()
+        raise RuntimeError("rank %d: %s" % (rank, "this rank failed: %r" % (failure,) if failure is not None
+                                            else "another rank failed; no pickle written"))
     max_tr = sweep.all_reduce_max(max([len(r["train_episode_rewards"]) for r in runs.values()] + [1]), device)
     vlen = sweep.full_vec_len(eval_shape, max_tr)
     vecs = [sweep.pack_full_run(i, runs[i], eval_shape, max_tr) for i in sorted(runs)]
@@ -302,7 +314,7 @@ def main_distributed(args, agent_json, env_json, train_env, test_env, env_params
                   "eval_interval_timesteps": env_json["EvalIntervalMilSteps"] * 1000000,
                   "episodes_per_eval": env_json["EvalEpisodes"],
                   "eval_episode_rewards": f["eval_episode_rewards"], "eval_episode_steps": f["eval_episode_steps"],
-                  "timesteps_at_eval": np.arange(f["eval_episode_rewards"].shape[0]) * interval,
+                  "timesteps_at_eval": f["timesteps_at_eval"],
                   "train_episode_steps": f["train_episode_steps"], "train_episode_rewards": f["train_episode_rewards"],
                   "total_train_episodes": f["total_train_episodes"], "eval_time": f["eval_time"],
                   "train_time": f["train_time"]}

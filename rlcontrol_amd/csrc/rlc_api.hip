@@ -27,6 +27,11 @@ template <typename T>
 int dmalloc(rlc_handle* h, T** out, size_t count, bool zero = true) { return rlc_h_malloc(h, out, count, zero); }
 
 int ensure_io_impl(rlc_handle* h, size_t bytes) {
+    // every CPU write into io_host goes through here first: wait for the copies a previous update_batch queued out of it
+    if (h->io_pending) {
+        RLC_HIP(hipStreamSynchronize(h->st));
+        h->io_pending = false;
+    }
     if (bytes > h->io_cap) {
         RLC_HIP(hipStreamSynchronize(h->st));
         if (h->io_dev) RLC_HIP(hipFree(h->io_dev));
@@ -128,6 +133,7 @@ int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, 
     h->idx_dev = nullptr; h->idx_cap = 0;
     h->io_dev = nullptr; h->io_cap = 0;
     h->io_host = nullptr; h->io_host_cap = 0;
+    h->io_pending = false;
     h->variant = 0;
     h->grad_taps = 0;
     h->has_env = false;
@@ -614,6 +620,7 @@ int rlc_ddpg_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const dou
     RLC_HIP(hipMemcpyAsync(h->rep.gs + slot * S, hf, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipMemcpyAsync(h->rep.gs2 + slot * S, hf + B * S, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipMemcpyAsync(h->rep.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
+    h->io_pending = true;
     return launch_update(h, agent, 1, 1, RLC_SRC_STAGING, nullptr);
 }
 

@@ -233,6 +233,7 @@ int rlc_naf_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const doub
     RLC_HIP(hipMemcpyAsync(h->rep.gs + slot * S, hf, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipMemcpyAsync(h->rep.gs2 + slot * S, hf + B * S, sizeof(float) * B * S, hipMemcpyHostToDevice, h->st));
     RLC_HIP(hipMemcpyAsync(h->rep.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
+    h->io_pending = true;
     return rlc_h_naf_launch_update(h, agent, 1, 1, RLC_SRC_STAGING, nullptr, nullptr);
 }
 

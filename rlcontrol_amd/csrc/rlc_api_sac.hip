@@ -267,6 +267,7 @@ int rlc_sac_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const doub
     RLC_HIP(hipMemcpyAsync(h->rep.ga + slot * A, hf + 2 * B * S, sizeof(float) * B * A, hipMemcpyHostToDevice, h->st));
     const float* eps_dev = nullptr;
     if (upload_eps(h, eps, B * A, &eps_dev, 0)) return 1;
+    h->io_pending = true;
     return rlc_h_sac_launch_update(h, agent, 1, 1, RLC_SRC_STAGING, nullptr, eps_dev, nullptr);
 }
 

@@ -20,6 +20,7 @@ struct rlc_handle {
     long long* idx_dev; size_t idx_cap;  // host-index upload buffer
     float* io_dev; size_t io_cap;        // act / qval / gather staging (device, bytes)
     void* io_host; size_t io_host_cap;   // pinned host staging (bytes)
+    bool io_pending;                     // async copies out of io_host may still be in flight (the update_batch paths)
     // ---- DDPG
     RlcDev dv;
     int variant;                         // requested kernel: 0 auto, 1 generic, 2 mfma

@@ -46,7 +46,7 @@ _SCALARS = ("random_seed", "total_train_episodes", "eval_time", "train_time")
 
 
 def full_vec_len(eval_shape, max_train_eps):
-    return 3 + len(_SCALARS) + 2 * eval_shape[0] * eval_shape[1] + 2 * max_train_eps
+    return 3 + len(_SCALARS) + 2 * eval_shape[0] * eval_shape[1] + eval_shape[0] + 2 * max_train_eps
 
 
 def pack_full_run(index, run_data, eval_shape, max_train_eps):
@@ -56,7 +56,8 @@ def pack_full_run(index, run_data, eval_shape, max_train_eps):
     evs = np.asarray(run_data["eval_episode_steps"], np.float64).reshape(-1)
     tr = np.asarray(run_data["train_episode_rewards"], np.float64).reshape(-1)
     trs = np.asarray(run_data["train_episode_steps"], np.float64).reshape(-1)
-    if ev.size > n_ev or tr.size > max_train_eps:
+    tae = np.asarray(run_data["timesteps_at_eval"], np.float64).reshape(-1)       # the values the run RECORDED
+    if ev.size > n_ev or tr.size > max_train_eps or tae.size > eval_shape[0]:
         raise ValueError("run %d does not fit the exchange record (%d evals, %d train episodes)" % (index, ev.size, tr.size))
     vec = np.full(full_vec_len(eval_shape, max_train_eps), np.nan)
     vec[0], vec[1], vec[2] = index, ev.size, tr.size
@@ -65,6 +66,7 @@ def pack_full_run(index, run_data, eval_shape, max_train_eps):
         vec[o] = float(run_data[k]); o += 1
     vec[o:o + ev.size] = ev; o += n_ev
     vec[o:o + evs.size] = evs; o += n_ev
+    vec[o:o + tae.size] = tae; o += eval_shape[0]
     vec[o:o + tr.size] = tr; o += max_train_eps
     vec[o:o + trs.size] = trs
     return vec
@@ -80,6 +82,8 @@ def unpack_full_run(vec, eval_shape, max_train_eps):
     rows = k_ev // eval_shape[1] if eval_shape[1] else 0
     out["eval_episode_rewards"] = vec[o:o + k_ev].reshape(rows, eval_shape[1]).copy(); o += n_ev
     out["eval_episode_steps"] = vec[o:o + k_ev].reshape(rows, eval_shape[1]).astype(np.int64); o += n_ev
+    tae = vec[o:o + eval_shape[0]]; o += eval_shape[0]
+    out["timesteps_at_eval"] = tae[~np.isnan(tae)].astype(np.int64)
     out["train_episode_rewards"] = vec[o:o + k_tr].copy(); o += max_train_eps
     out["train_episode_steps"] = vec[o:o + k_tr].astype(np.int64)
     return int(vec[0]), out

@@ -209,3 +209,46 @@ def test_bench_single_rank_reduce_is_identity():
     roof, hbm = bench.roofline_record(73.2e6, 2634064.0, 256 * 32, 10.6e-3)
     assert abs(roof["frac"] - 73.2e6 * 8192 / 10.6e-3 / 157.3e12) < 1e-12 and roof["bound"] == "mfma"
     assert abs(hbm["achieved"] - 2634064.0 * 8192 / 10.6e-3 / 1e9) < 1e-6
+
+
+# ---- a rank that fails must not leave the others waiting in the collective -------------------------------------
+class _FailingAgent(_FakeAgent):
+    def update(self, *a):
+        raise RuntimeError("boom on this rank")
+
+
+def _main_worker_one_rank_fails(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    import main as drv
+    drv.create_agent = (lambda name, cfg: _FailingAgent(cfg)) if rank == 1 else (lambda name, cfg: _FakeAgent(cfg))
+    envf = os.path.join(tmp, "Pendulum-v0.json")
+    if rank == 0:
+        with open(envf, "w") as f:
+            json.dump(ENV2, f)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    try:
+        drv.main(["--env_json", envf, "--agent_json", os.path.join(ROOT, "jsonfiles/agent/ddpg.json"),
+                  "--indices", "0", "7", "28", "--save_dir", os.path.join(tmp, "res"), "--quiet"])
+    except RuntimeError as e:
+        with open(os.path.join(tmp, "err%d.txt" % rank), "w") as f:
+            f.write(str(e))
+        sys.exit(3)
+    sys.exit(0)
+
+
+def test_failing_rank_ends_the_sweep_on_every_rank_promptly(tmp_path):
+    ctx = mp.get_context("spawn")
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_main_worker_one_rank_fails, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 3                      # both ranks raised -- nobody hangs in the all-gather
+    assert "this rank failed" in (tmp_path / "err1.txt").read_text()
+    assert "another rank failed" in (tmp_path / "err0.txt").read_text()
+    assert not (tmp_path / "res" / "Pendulum-v0_ddpgresults" / "data_0_7_28.pkl").exists()
