@@ -53,7 +53,10 @@ typedef struct rlc_ddpg_config {
     int32_t batch_size;      /* config.batch_size (reference default 32, utils/config.py:12) */
     int64_t buffer_size;     /* config.buffer_size: replay capacity PER AGENT (utils/config.py:13) */
     int32_t clip_state;      /* 1 when config.norm_type != 'none' (hydra_ddpg_network.py:86-87, quirk Q6) */
-    int32_t reserved0;
+    int32_t norm_type;       /* RLC_NORM_NONE: config.norm_type 'none' / 'input_norm' (activation only);
+                              * RLC_NORM_LAYER: 'layer' -- tf.contrib.layers.layer_norm(center, scale) before every
+                              * hidden relu (agents/network/base_network.py:53-56); each layer adds beta then gamma to
+                              * the blob.  'batch' (base_network.py:57-59) is not implemented: create fails. */
     float tau;               /* config.tau */
     float reserved1;
     const float* state_min;  /* [state_dim] */
@@ -64,8 +67,15 @@ typedef struct rlc_ddpg_config {
     const float* critic_lr;  /* [n_agents] */
     const uint64_t* seed;    /* [n_agents] Philox keys of the device sampler / OU generator */
     float ou_theta, ou_mu, ou_sigma; /* utils/config.py:19-21 (device OU generator) */
-    int32_t reserved2;
+    int32_t separate_networks; /* 0: the hydra network agents/DDPG.py builds (shared first layer, :26);
+                                * 1: separate actor / critic networks (agents/network/actor_network.py:73-96,
+                                *    critic_network.py:77-99; commented out in agents/DDPG.py:8-9,24-25): the critic
+                                *    gets a first layer of its own.  Blob: W1 b1 [l1b l1g] Wa2 ba2 [l2b l2g] Wa3 ba3
+                                *    [Wc1 bc1 [lcb lcg]] Wc2 bc2 [l3b l3g] Wc3 bc3 */
 } rlc_ddpg_config;
+
+#define RLC_NORM_NONE 0
+#define RLC_NORM_LAYER 1
 
 const char* rlc_last_error(void);
 int rlc_version(void);

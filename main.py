@@ -97,6 +97,12 @@ def _make_population(agent_name, members, arg_params):
     c0 = members[0][3]
     seeds = [np.uint64(m[3].random_seed) for m in members]
     device = int(arg_params.get("device", 0))
+    # the on-device loop implements the shipped jsons' input handling only; a norm_type it does not apply must never be
+    # reported in the pickle's agent_params as if it had run (the reference applies layer / batch norm for those values,
+    # agents/network/base_network.py:53-65)
+    from rlcontrol_amd.agents.network.base_network_manager import check_norm_type
+    check_norm_type(c0, agent_name + " --device_rollout",
+                    ('input_norm',) if agent_name == "SoftActorCritic" else ('none', 'input_norm'))
     if agent_name == "DDPG":
         from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
         if c0.exploration_policy != 'ou_noise':
@@ -116,6 +122,10 @@ def _make_population(agent_name, members, arg_params):
         from rlcontrol_amd.hip_naf import NAFPopulation, init_params
         if c0.exploration_policy != 'none':
             raise RuntimeError("the device loop implements NAF's own covariance exploration (exploration_policy 'none')")
+        if not np.allclose(np.asarray(c0.action_min, np.float64), -np.asarray(c0.action_max, np.float64)):
+            # the reference clips the draw to [action_min, action_max] (naf_network.py:176); the device draw clips to
+            # +-action_max, which is the same thing only for a symmetric box
+            raise ValueError("the NAF device loop needs a symmetric action box (action_min == -action_max)")
         pop = NAFPopulation(
             n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, l1_dim=c0.l1_dim, l2_dim=c0.l2_dim,
             batch_size=c0.batch_size, buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min,

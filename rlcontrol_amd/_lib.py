@@ -47,14 +47,14 @@ class rlc_ddpg_config(ctypes.Structure):
         ("state_dim", ctypes.c_int32), ("action_dim", ctypes.c_int32),
         ("shared_l1_dim", ctypes.c_int32), ("actor_l2_dim", ctypes.c_int32), ("critic_l2_dim", ctypes.c_int32),
         ("batch_size", ctypes.c_int32), ("buffer_size", ctypes.c_int64),
-        ("clip_state", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("clip_state", ctypes.c_int32), ("norm_type", ctypes.c_int32),
         ("tau", ctypes.c_float), ("reserved1", ctypes.c_float),
         ("state_min", ctypes.POINTER(ctypes.c_float)), ("state_max", ctypes.POINTER(ctypes.c_float)),
         ("action_min", ctypes.POINTER(ctypes.c_float)), ("action_max", ctypes.POINTER(ctypes.c_float)),
         ("actor_lr", ctypes.POINTER(ctypes.c_float)), ("critic_lr", ctypes.POINTER(ctypes.c_float)),
         ("seed", ctypes.POINTER(ctypes.c_uint64)),
         ("ou_theta", ctypes.c_float), ("ou_mu", ctypes.c_float), ("ou_sigma", ctypes.c_float),
-        ("reserved2", ctypes.c_int32),
+        ("separate_networks", ctypes.c_int32),
     ]
 
 

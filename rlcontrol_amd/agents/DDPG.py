@@ -13,15 +13,17 @@ Added for the fused path: ``update_from_replay(logical_indices)`` and ``device_r
 import numpy as np
 
 from .base_agent import BaseAgent
-from .network.base_network_manager import BaseNetwork_Manager
+from .network.base_network_manager import BaseNetwork_Manager, check_norm_type
 from ..hip_ddpg import DDPGPopulation, init_params
 
 
 class DDPG_Network_Manager(BaseNetwork_Manager):
     def __init__(self, config):
         super(DDPG_Network_Manager, self).__init__(config)
-        assert config.norm_type in ('none', 'input_norm'), \
-            "only norm_type 'input_norm'/'none' are accelerated (all shipped jsons use input_norm)"
+        check_norm_type(config, "DDPG", ('none', 'input_norm', 'layer'))
+        # `network: separate` selects the reference's actor_network.py / critic_network.py pair (commented out in
+        # agents/DDPG.py:8-9,24-25); the default is the hydra network it builds (agents/DDPG.py:26)
+        separate = getattr(config, "network", "hydra") == "separate"
         self.population = DDPGPopulation(
             n_agents=1, state_dim=config.state_dim, action_dim=config.action_dim,
             shared_l1_dim=config.shared_l1_dim, actor_l2_dim=config.actor_l2_dim,
@@ -33,13 +35,14 @@ class DDPG_Network_Manager(BaseNetwork_Manager):
             seeds=[np.uint64(config.random_seed)],
             clip_state=(config.norm_type != 'none'),
             ou_theta=config.ou_theta, ou_mu=config.ou_mu, ou_sigma=config.ou_sigma,
-            device=int(getattr(config, "device", 0)))
+            device=int(getattr(config, "device", 0)),
+            norm_type=config.norm_type, separate_networks=separate)
         kernel = getattr(config, "hip_kernel", "auto")
         if kernel != "auto":
             self.population.set_kernel(kernel)
         # sess.run(global_variables_initializer()) + init_target_network() (agents/DDPG.py:28-32)
         theta0 = init_params(config.state_dim, config.action_dim, config.shared_l1_dim, config.actor_l2_dim,
-                             config.critic_l2_dim, config.random_seed)
+                             config.critic_l2_dim, config.random_seed, config.norm_type, separate)
         self.population.set_params(0, theta0, init_target=True)
 
     def device_replay(self):

@@ -9,14 +9,14 @@ reference.  Evaluation returns the greedy action.
 import numpy as np
 
 from .base_agent import BaseAgent
-from .network.base_network_manager import BaseNetwork_Manager
+from .network.base_network_manager import BaseNetwork_Manager, check_norm_type
 from ..hip_naf import NAFPopulation, init_params
 
 
 class NAF_Network_Manager(BaseNetwork_Manager):
     def __init__(self, config):
         super(NAF_Network_Manager, self).__init__(config)
-        assert config.norm_type in ('none', 'input_norm'), "only norm_type 'input_norm'/'none' are accelerated"
+        check_norm_type(config, "NAF", ('none', 'input_norm'))
         self.rng = np.random.RandomState(config.random_seed)      # NAF_Network.rng (naf_network.py:10)
         self.noise_scale = config.noise_scale
         self.population = NAFPopulation(

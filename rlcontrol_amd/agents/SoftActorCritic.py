@@ -10,7 +10,7 @@ draws it with tf.random_normal, which cannot be reproduced without TensorFlow: s
 import numpy as np
 
 from .base_agent import BaseAgent
-from .network.base_network_manager import BaseNetwork_Manager
+from .network.base_network_manager import BaseNetwork_Manager, check_norm_type
 from ..hip_sac import SACPopulation, init_params
 
 
@@ -24,6 +24,7 @@ class SoftActorCritic_Network_Manager(BaseNetwork_Manager):
         if config.norm_type == 'none':
             # the reference leaves `inputs` undefined in that case (quirk Q10, sac_network.py:175-178)
             raise ValueError("SoftActorCritic needs norm_type != 'none'")
+        check_norm_type(config, "SoftActorCritic", ('input_norm',))
         self.population = SACPopulation(
             n_agents=1, state_dim=config.state_dim, action_dim=config.action_dim,
             actor_l1_dim=config.actor_l1_dim, actor_l2_dim=config.actor_l2_dim,

@@ -12,6 +12,14 @@ _LOG_FLAGS = ("write_log", "write_plot", "writer")
 _COUNTERS = ("train_global_steps", "eval_global_steps", "train_ep_count", "eval_ep_count")
 
 
+def check_norm_type(config, agent_name, supported):
+    """The reference accepts norm_type none / input_norm / layer / batch from any json (base_network.py:53-65).  The HIP
+    path implements a subset per agent; anything else is refused loudly (never silently run as input_norm)."""
+    if config.norm_type not in supported:
+        raise ValueError("%s: norm_type %r is not implemented in the HIP path (implemented: %s)" %
+                         (agent_name, config.norm_type, ", ".join(repr(s) for s in supported)))
+
+
 class BaseNetwork_Manager(object):
     def __init__(self, config):
         self.random_seed = config.random_seed

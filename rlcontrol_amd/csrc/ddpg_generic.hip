@@ -25,6 +25,7 @@ struct Lds {
     int* pool;
     int* dups;
     float* pol;       // scratch of the on-device training step (ddpg_rollout_device.h)
+    float* rstd;      // [4][B] reciprocal standard deviations of the layer-norm rows
 };
 
 __host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* base, Lds* out) {
@@ -51,7 +52,9 @@ __host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* bas
     int* pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     int* dups = (int*)take(sizeof(int) * 4);
     float* pol = (float*)take(sizeof(float) * (ddpg_policy_lds_floats(d) + 4));
+    float* rstd = (float*)take(sizeof(float) * 4 * B);
     if (out) {
+        out->rstd = rstd;
         out->r = r; out->g = g; out->idx = idx; out->x = x; out->x2 = x2; out->a = a; out->aout = aout;
         out->mu = mu; out->dqda = dqda; out->dz = dz; out->q = q; out->y = y; out->dq = dq;
         out->pool = pool; out->dups = dups; out->pol = pol;
@@ -75,15 +78,46 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
     float* th = dv.theta + (size_t)agent * d.Ppad;
     float* tt = dv.theta_t + (size_t)agent * d.Ppad;
     float* sc = dv.scratch + (size_t)agent * dv.scratch_stride;
-    float* h1 = sc;
-    float* h2 = h1 + (size_t)B * H1;
-    float* g2 = h2 + (size_t)B * HA;
-    float* d2 = g2 + (size_t)B * HC;
-    float* dh1 = d2 + (size_t)B * max(HA, HC);
+    const int HM = max(HA, HC), NORM = d.norm, SEP = d.sep;
+    float* h1 = sc;                  sc += (size_t)B * H1;
+    float* h2 = sc;                  sc += (size_t)B * HA;
+    float* g2 = sc;                  sc += (size_t)B * HC;
+    float* d2 = sc;                  sc += (size_t)B * HM;
+    float* dh1 = sc;                 sc += (size_t)B * H1;
+    // layer norm keeps the normalised activations of the three hidden layers for the backward pass; separate
+    // networks give the critic a first layer (c1) of its own -- otherwise it reads the shared h1
+    float* n1 = sc;                  if (NORM) sc += (size_t)B * H1;
+    float* n2 = sc;                  if (NORM) sc += (size_t)B * HA;
+    float* n3 = sc;                  if (NORM) sc += (size_t)B * HC;
+    float* c1 = SEP ? sc : h1;       if (SEP) sc += (size_t)B * H1;
+    float* nc = SEP ? sc : n1;       if (SEP && NORM) sc += (size_t)B * H1;
+    float* r1 = L.rstd; float* r2 = r1 + B; float* r3 = r2 + B; float* rc = SEP ? r3 + B : r1;
     float* pw = dv.pw + agent * 4;
     const float lr_a = dv.actor_lr[agent], lr_c = dv.critic_lr[agent];
     float* tap_gc = grad_taps ? dv.tap_gc + (size_t)agent * d.Ppad : nullptr;
     float* tap_ga = grad_taps ? dv.tap_ga + (size_t)agent * d.Ppad : nullptr;
+    // hidden layer: Y = relu([LN](X.W[0:K] + E.W[K:K+Ke] + b)); nh / rs (layer norm only) keep what its backward needs
+    auto hidden = [&](const float* X, int K, const float* E, int Ke, const float* P, int oW, int ob, int olb, int olg, int N,
+                      float* Y, float* nh, float* rs) {
+        blk_dense(X, K, K, E, Ke, P + oW, P + ob, N, Y, N, B, NORM ? 0 : 1);
+        if (NORM) {
+            __syncthreads();
+            blk_layernorm_relu(Y, N, B, P + olb, P + olg, nh, rs);
+        }
+        __syncthreads();
+    };
+    // layer-norm backward of a hidden layer whose masked output gradient is dY: returns this thread's (gamma, beta)
+    // gradient column sums and turns dY into the gradient w.r.t. the linear output, with the PRE-step gamma
+    auto ln_bwd = [&](float* dY, const float* nh, const float* rs, int olg, int N, float& gg, float& gb) {
+        if (!NORM) return;
+        blk_layernorm_param_grads(dY, nh, N, B, gg, gb);
+        __syncthreads();
+        blk_layernorm_bwd_rows(dY, nh, rs, th + olg, N, B);
+        __syncthreads();
+    };
+    auto ln_adam = [&](const AdamCtx& c, int olb, int olg, int N, float gg, float gb) {
+        if (NORM && tid < N) { adam_apply(c, olg + tid, gg); adam_apply(c, olb + tid, gb); }
+    };
 
     for (int u = 0; u < n_updates; u++) {
         if (rollout) {
@@ -122,16 +156,14 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         __syncthreads();
 
         // ---- steps 1-2: target actor / critic on s' (DDPG.py:77) ----
-        blk_dense(L.x2, S, S, nullptr, 0, tt + d.oW1, tt + d.ob1, H1, h1, H1, B, 1);
-        __syncthreads();
-        blk_dense(h1, H1, H1, nullptr, 0, tt + d.oWa2, tt + d.oba2, HA, h2, HA, B, 1);
-        __syncthreads();
+        hidden(L.x2, S, nullptr, 0, tt, d.oW1, d.ob1, d.oL1b, d.oL1g, H1, h1, nullptr, nullptr);
+        hidden(h1, H1, nullptr, 0, tt, d.oWa2, d.oba2, d.oL2b, d.oL2g, HA, h2, nullptr, nullptr);
         blk_dense(h2, HA, HA, nullptr, 0, tt + d.oWa3, tt + d.oba3, A, L.mu, A, B, 2);
         __syncthreads();
         for (int i = tid; i < B * A; i += kThreads) L.aout[i] = L.mu[i] * dv.amax[i % A];
         __syncthreads();
-        blk_dense(h1, H1, H1, L.aout, A, tt + d.oWc2, tt + d.obc2, HC, g2, HC, B, 1);
-        __syncthreads();
+        if (SEP) hidden(L.x2, S, nullptr, 0, tt, d.oWc1, d.obc1, d.oLcb, d.oLcg, H1, c1, nullptr, nullptr);
+        hidden(c1, H1, L.aout, A, tt, d.oWc2, d.obc2, d.oL3b, d.oL3g, HC, g2, nullptr, nullptr);
         blk_dense(g2, HC, HC, nullptr, 0, tt + d.oWc3, tt + d.obc3, 1, L.q, 1, B, 0);
         __syncthreads();
         // TD target in float64, then the fp32 placeholder cast (DDPG.py:80-84)
@@ -143,10 +175,8 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         __syncthreads();
 
         // ---- step 3: critic step (hydra_ddpg_network.py:71-72) ----
-        blk_dense(L.x, S, S, nullptr, 0, th + d.oW1, th + d.ob1, H1, h1, H1, B, 1);
-        __syncthreads();
-        blk_dense(h1, H1, H1, L.a, A, th + d.oWc2, th + d.obc2, HC, g2, HC, B, 1);
-        __syncthreads();
+        hidden(L.x, S, nullptr, 0, th, d.oWc1, d.obc1, d.oLcb, d.oLcg, H1, c1, nc, rc);
+        hidden(c1, H1, L.a, A, th, d.oWc2, d.obc2, d.oL3b, d.oL3g, HC, g2, n3, r3);
         blk_dense(g2, HC, HC, nullptr, 0, th + d.oWc3, th + d.obc3, 1, L.q, 1, B, 0);
         __syncthreads();
         for (int b = tid; b < B; b += kThreads) {
@@ -159,23 +189,26 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
             d2[it] = g2[it] > 0.0f ? L.dq[b] * th[d.oWc3 + n] : 0.0f;
         }
         __syncthreads();
-        blk_dense_bwd_input(d2, HC, th + d.oWc2, h1, H1, dh1, B);    // uses the pre-step Wc2
+        float gg3 = 0.f, gb3 = 0.f, ggc = 0.f, gbc = 0.f;
+        ln_bwd(d2, n3, r3, d.oL3g, HC, gg3, gb3);
+        blk_dense_bwd_input(d2, HC, th + d.oWc2, c1, H1, dh1, B);    // uses the pre-step Wc2
         __syncthreads();
+        ln_bwd(dh1, nc, rc, d.oLcg, H1, ggc, gbc);
         {
             const AdamCtx c = {th, dv.m_c + (size_t)agent * d.Ppad, dv.v_c + (size_t)agent * d.Ppad,
                                adam_alpha(lr_c, pw[2], pw[3]), tap_gc};
             blk_dense_grad_adam(g2, HC, HC, nullptr, 0, L.dq, 1, B, c, d.oWc3, d.obc3);
-            blk_dense_grad_adam(h1, H1, H1, L.a, A, d2, HC, B, c, d.oWc2, d.obc2);
-            blk_dense_grad_adam(L.x, S, S, nullptr, 0, dh1, H1, B, c, d.oW1, d.ob1);
+            blk_dense_grad_adam(c1, H1, H1, L.a, A, d2, HC, B, c, d.oWc2, d.obc2);
+            blk_dense_grad_adam(L.x, S, S, nullptr, 0, dh1, H1, B, c, d.oWc1, d.obc1);
+            ln_adam(c, d.oL3b, d.oL3g, HC, gg3, gb3);
+            ln_adam(c, d.oLcb, d.oLcg, H1, ggc, gbc);
         }
         __syncthreads();
         if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
 
-        // ---- step 4: actor forward with the updated trunk (DDPG.py:90) ----
-        blk_dense(L.x, S, S, nullptr, 0, th + d.oW1, th + d.ob1, H1, h1, H1, B, 1);
-        __syncthreads();
-        blk_dense(h1, H1, H1, nullptr, 0, th + d.oWa2, th + d.oba2, HA, h2, HA, B, 1);
-        __syncthreads();
+        // ---- step 4: actor forward with the updated first layer (DDPG.py:90) ----
+        hidden(L.x, S, nullptr, 0, th, d.oW1, d.ob1, d.oL1b, d.oL1g, H1, h1, n1, r1);
+        hidden(h1, H1, nullptr, 0, th, d.oWa2, d.oba2, d.oL2b, d.oL2g, HA, h2, n2, r2);
         blk_dense(h2, HA, HA, nullptr, 0, th + d.oWa3, th + d.oba3, A, L.mu, A, B, 2);
         __syncthreads();
         for (int i = tid; i < B * A; i += kThreads) {
@@ -185,13 +218,24 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         }
         __syncthreads();
         // ---- step 5: dQ/da at the scaled action with the updated critic (DDPG.py:91) ----
-        blk_dense(h1, H1, H1, L.aout, A, th + d.oWc2, th + d.obc2, HC, g2, HC, B, 1);
-        __syncthreads();
+        if (SEP) hidden(L.x, S, nullptr, 0, th, d.oWc1, d.obc1, d.oLcb, d.oLcg, H1, c1, nullptr, nullptr);
+        hidden(c1, H1, L.aout, A, th, d.oWc2, d.obc2, d.oL3b, d.oL3g, HC, g2, n3, r3);
+        if (NORM) {
+            // through the layer norm: dz3 = LN'(relu'(.) * Wc3), then its action rows
+            for (int it = tid; it < B * HC; it += kThreads) d2[it] = g2[it] > 0.0f ? th[d.oWc3 + it % HC] : 0.0f;
+            __syncthreads();
+            blk_layernorm_bwd_rows(d2, n3, r3, th + d.oL3g, HC, B);
+            __syncthreads();
+        }
         for (int it = tid; it < B * A; it += kThreads) {
             const int b = it / A, j = it % A;
             float acc = 0.0f;
-            for (int n = 0; n < HC; n++)
-                if (g2[(size_t)b * HC + n] > 0.0f) acc += th[d.oWc3 + n] * th[d.oWc2 + (size_t)(H1 + j) * HC + n];
+            if (NORM) {
+                for (int n = 0; n < HC; n++) acc += d2[(size_t)b * HC + n] * th[d.oWc2 + (size_t)(H1 + j) * HC + n];
+            } else {
+                for (int n = 0; n < HC; n++)
+                    if (g2[(size_t)b * HC + n] > 0.0f) acc += th[d.oWc3 + n] * th[d.oWc2 + (size_t)(H1 + j) * HC + n];
+            }
             L.dqda[it] = acc;
             dv.tap_dqda[(size_t)agent * RLC_MAX_BATCH * A + it] = acc;
             L.dz[it] = -acc * (1.0f - L.mu[it] * L.mu[it]);          // grad_ys = -dQ/da on tanh output (Q3)
@@ -205,18 +249,23 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
             d2[it] = h2[it] > 0.0f ? acc : 0.0f;
         }
         __syncthreads();
+        float gg2 = 0.f, gb2 = 0.f, gg1 = 0.f, gb1 = 0.f;
+        ln_bwd(d2, n2, r2, d.oL2g, HA, gg2, gb2);
         blk_dense_bwd_input(d2, HA, th + d.oWa2, h1, H1, dh1, B);
         __syncthreads();
+        ln_bwd(dh1, n1, r1, d.oL1g, H1, gg1, gb1);
         {
             const AdamCtx c = {th, dv.m_a + (size_t)agent * d.Ppad, dv.v_a + (size_t)agent * d.Ppad,
                                adam_alpha(lr_a, pw[0], pw[1]), tap_ga};
             blk_dense_grad_adam(h2, HA, HA, nullptr, 0, L.dz, A, B, c, d.oWa3, d.oba3);
             blk_dense_grad_adam(h1, H1, H1, nullptr, 0, d2, HA, B, c, d.oWa2, d.oba2);
             blk_dense_grad_adam(L.x, S, S, nullptr, 0, dh1, H1, B, c, d.oW1, d.ob1);
+            ln_adam(c, d.oL2b, d.oL2g, HA, gg2, gb2);
+            ln_adam(c, d.oL1b, d.oL1g, H1, gg1, gb1);
         }
         __syncthreads();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
-        // ---- step 7: Polyak on all ten tensors (hydra_ddpg_network.py:29) ----
+        // ---- step 7: Polyak on every tensor (hydra_ddpg_network.py:29) ----
         for (int p = tid; p < d.Pdev; p += kThreads) {
             const float t = tt[p];
             tt[p] = t + dv.tau * (th[p] - t);
@@ -263,26 +312,35 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_qval_kernel(RlcDev dv, int 
     const int tid = threadIdx.x, row = blockIdx.x;
     float* x = (float*)smem;
     float* h1 = x + ((S + A + 3) & ~3);
-    float* red = h1 + ((H1 + 3) & ~3);
+    float* g2 = h1 + ((H1 + 3) & ~3);
+    float* red = g2 + ((HC + 3) & ~3);
     const float* th = dv.theta + (size_t)agent * d.Ppad;
     for (int i = tid; i < S; i += kThreads)
         x[i] = clip_state_val(states[(size_t)row * S + i], dv.clip_state, dv.smin[i], dv.smax[i]);
     for (int j = tid; j < A; j += kThreads) x[S + j] = actions[(size_t)row * A + j];
     __syncthreads();
+    // the critic's first layer: the shared one of the hydra network, its own with separate networks
     for (int k = tid; k < H1; k += kThreads) {
         float acc = 0.0f;
-        for (int i = 0; i < S; i++) acc += x[i] * th[d.oW1 + i * H1 + k];
-        h1[k] = fmaxf(acc + th[d.ob1 + k], 0.0f);
+        for (int i = 0; i < S; i++) acc += x[i] * th[d.oWc1 + i * H1 + k];
+        acc += th[d.obc1 + k];
+        h1[k] = d.norm ? acc : fmaxf(acc, 0.0f);
     }
     __syncthreads();
-    float part = 0.0f;
+    if (d.norm) rlc_row_layernorm_relu(h1, H1, th + d.oLcb, th + d.oLcg, red);
     for (int n = tid; n < HC; n += kThreads) {
         float acc = 0.0f;
         for (int k = 0; k < H1; k++) acc += h1[k] * th[d.oWc2 + rlc_widx(d.blocked, k, n, HC)];
         for (int j = 0; j < A; j++) acc += x[S + j] * th[d.oWc2 + rlc_widx(d.blocked, d.arow0 + j, n, HC)];
-        part += fmaxf(acc + th[d.obc2 + n], 0.0f) * th[d.oWc3 + n];
+        acc += th[d.obc2 + n];
+        g2[n] = d.norm ? acc : fmaxf(acc, 0.0f);
     }
+    __syncthreads();
+    if (d.norm) rlc_row_layernorm_relu(g2, HC, th + d.oL3b, th + d.oL3g, red);
+    float part = 0.0f;
+    for (int n = tid; n < HC; n += kThreads) part += g2[n] * th[d.oWc3 + n];
     for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, RLC_WAVE);
+    __syncthreads();
     if (tid % RLC_WAVE == 0) red[tid / RLC_WAVE] = part;
     __syncthreads();
     if (tid == 0) {
@@ -296,7 +354,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_qval_kernel(RlcDev dv, int 
 
 size_t rlc_generic_scratch_floats(const RlcDims& d) {
     const size_t B = d.B;
-    return B * d.H1 * 2 + B * d.HA + B * d.HC + B * (size_t)(d.HA > d.HC ? d.HA : d.HC);
+    size_t n = B * d.H1 * 2 + B * d.HA + B * d.HC + B * (size_t)(d.HA > d.HC ? d.HA : d.HC);
+    if (d.norm) n += B * ((size_t)d.H1 + d.HA + d.HC);
+    if (d.sep) n += B * (size_t)d.H1 * (d.norm ? 2 : 1);
+    return n;
 }
 
 int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
@@ -329,7 +390,7 @@ int rlc_launch_reset_noise(const RlcDev& dv, int first_agent, int n, hipStream_t
 
 int rlc_launch_qval(const RlcDev& dv, int agent, int n, const float* states_dev, const float* actions_dev,
                     float* out_dev, hipStream_t st) {
-    const size_t lds = sizeof(float) * (((dv.d.S + dv.d.A + 3) & ~3) + ((dv.d.H1 + 3) & ~3) + 8);
+    const size_t lds = sizeof(float) * (((dv.d.S + dv.d.A + 3) & ~3) + ((dv.d.H1 + 3) & ~3) + ((dv.d.HC + 3) & ~3) + 40);
     hipLaunchKernelGGL(rlc_ddpg_qval_kernel, dim3(n), dim3(kThreads), lds, st, dv, agent, states_dev, actions_dev,
                        out_dev);
     RLC_HIP(hipGetLastError());

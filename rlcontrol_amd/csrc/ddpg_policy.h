@@ -8,13 +8,13 @@
 
 #define RLC_POLICY_THREADS 256
 
-// LDS floats needed by ddpg_greedy_forward: x | h1 | h2 | act
+// LDS floats needed by ddpg_greedy_forward: x | h1 | h2 | act | red (layer-norm row reductions)
 __host__ __device__ inline size_t ddpg_policy_lds_floats(const RlcDims& d) {
-    return (size_t)((d.S + 3) & ~3) + ((d.H1 + 3) & ~3) + ((d.HA + 3) & ~3) + ((d.A + 3) & ~3);
+    return (size_t)((d.S + 3) & ~3) + ((d.H1 + 3) & ~3) + ((d.HA + 3) & ~3) + ((d.A + 3) & ~3) + 40;
 }
 
 struct DdpgPolicyLds {
-    float *x, *h1, *h2, *act;
+    float *x, *h1, *h2, *act, *red;
 };
 
 __device__ inline DdpgPolicyLds ddpg_policy_carve(const RlcDims& d, float* base) {
@@ -23,6 +23,7 @@ __device__ inline DdpgPolicyLds ddpg_policy_carve(const RlcDims& d, float* base)
     L.h1 = L.x + ((d.S + 3) & ~3);
     L.h2 = L.h1 + ((d.H1 + 3) & ~3);
     L.act = L.h2 + ((d.HA + 3) & ~3);
+    L.red = L.act + ((d.A + 3) & ~3);
     return L;
 }
 
@@ -34,30 +35,18 @@ __device__ inline void ddpg_greedy_forward(const RlcDims& d, const float* th, co
                                            const float* amax) {
     const int S = d.S, A = d.A, H1 = d.H1, HA = d.HA;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    constexpr int KC = 16;
     __syncthreads();
     for (int k = tid; k < H1; k += nthr) {
         float acc = 0.0f;
         for (int i = 0; i < S; i++) acc += L.x[i] * th[d.oW1 + i * H1 + k];
-        L.h1[k] = fmaxf(acc + th[d.ob1 + k], 0.0f);
+        acc += th[d.ob1 + k];
+        L.h1[k] = d.norm ? acc : fmaxf(acc, 0.0f);
     }
     __syncthreads();
-    for (int n = tid; n < HA; n += nthr) {
-        const RlcWCol wcol = rlc_wcol(th + d.oWa2, d.blocked, n, HA);
-        float acc = 0.0f;
-        int k0 = 0;
-        for (; k0 + KC <= H1; k0 += KC) {     // KC = 16: a chunk never straddles a 16-row block
-            const float* wp = wcol.at(k0);
-            float w[KC];
-#pragma unroll
-            for (int i = 0; i < KC; i++) w[i] = wp[(size_t)i * wcol.step];
-#pragma unroll
-            for (int i = 0; i < KC; i++) acc += L.h1[k0 + i] * w[i];
-        }
-        for (; k0 < H1; k0++) acc += L.h1[k0] * *wcol.at(k0);
-        L.h2[n] = fmaxf(acc + th[d.oba2 + n], 0.0f);
-    }
+    if (d.norm) rlc_row_layernorm_relu(L.h1, H1, th + d.oL1b, th + d.oL1g, L.red);
+    rlc_hidden_forward_row(th + d.oWa2, d.blocked, th + d.oba2, L.h1, H1, HA, L.h2, !d.norm);
     __syncthreads();
+    if (d.norm) rlc_row_layernorm_relu(L.h2, HA, th + d.oL2b, th + d.oL2g, L.red);
     // one wave per output action: 64-lane shuffle reduction over HA
     const int wave = tid / RLC_WAVE, lane = tid % RLC_WAVE;
     for (int j = wave; j < A; j += nthr / RLC_WAVE) {

@@ -193,6 +193,62 @@ __device__ inline void blk_dense_bwd_input(const float* dY, int N, const float* 
     }
 }
 
+// ---- tf.contrib.layers.layer_norm (agents/network/base_network.py:53-56) on the rows of a [B, N] activation ----
+// One wave per row, lane l holds features l, l+64, ...; row sums go through a fixed shuffle tree (deterministic).
+#define RLC_LN_EPS 1e-12f
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// Z (in: x.W + b, out: relu(gamma * nhat + beta)), nhat = (z - mean) * rsqrt(var + eps) and rstd kept for the
+// backward pass when the pointers are non-null
+__device__ inline void blk_layernorm_relu(float* Z, int N, int B, const float* beta, const float* gamma, float* nhat,
+                                          float* rstd) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kThreads >> 6;
+    for (int r = wave; r < B; r += nw) {
+        float* z = Z + (size_t)r * N;
+        float s = 0.0f;
+        for (int n = lane; n < N; n += 64) s += z[n];
+        const float mean = wave_sum64(s) / (float)N;
+        float q = 0.0f;
+        for (int n = lane; n < N; n += 64) { const float c = z[n] - mean; q += c * c; }
+        const float rs = 1.0f / sqrtf(wave_sum64(q) / (float)N + RLC_LN_EPS);
+        if (rstd && lane == 0) rstd[r] = rs;
+        for (int n = lane; n < N; n += 64) {
+            const float nh = (z[n] - mean) * rs;
+            if (nhat) nhat[(size_t)r * N + n] = nh;
+            z[n] = fmaxf(nh * gamma[n] + beta[n], 0.0f);
+        }
+    }
+}
+// dY [B, N] = gradient w.r.t. gamma * nhat + beta (relu mask applied).  Thread n < N returns the column sums that
+// are the gradients of gamma[n] and beta[n] (call before blk_layernorm_bwd_rows overwrites dY).
+__device__ inline void blk_layernorm_param_grads(const float* dY, const float* nhat, int N, int B, float& g_gamma,
+                                                 float& g_beta) {
+    g_gamma = 0.0f; g_beta = 0.0f;
+    const int n = threadIdx.x;
+    if (n < N)
+        for (int b = 0; b < B; b++) {
+            const float t = dY[(size_t)b * N + n];
+            g_gamma += t * nhat[(size_t)b * N + n];
+            g_beta += t;
+        }
+}
+// dY -> gradient w.r.t. the layer's linear output, row by row: rstd * (g - mean(g) - nhat * mean(g * nhat)), g = dY * gamma
+__device__ inline void blk_layernorm_bwd_rows(float* dY, const float* nhat, const float* rstd, const float* gamma, int N,
+                                              int B) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = kThreads >> 6;
+    for (int r = wave; r < B; r += nw) {
+        float* dy = dY + (size_t)r * N;
+        const float* nh = nhat + (size_t)r * N;
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int n = lane; n < N; n += 64) { const float gq = dy[n] * gamma[n]; s1 += gq; s2 += gq * nh[n]; }
+        const float m1 = wave_sum64(s1) / (float)N, m2 = wave_sum64(s2) / (float)N, rs = rstd[r];
+        for (int n = lane; n < N; n += 64) dy[n] = rs * (dy[n] * gamma[n] - m1 - nh[n] * m2);
+    }
+}
+
 struct AdamCtx {
     float* theta; float* m; float* v; float alpha; float* tap;   // tap may be null
 };

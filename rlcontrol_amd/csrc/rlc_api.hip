@@ -201,8 +201,14 @@ int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_handle** out) {
 
     RlcDev& dv = h->dv;
     // the tile-blocked weight layout goes with the MFMA kernel (the default whenever it supports the shape)
+    RLC_REQUIRE(cfg->norm_type == RLC_NORM_NONE || cfg->norm_type == RLC_NORM_LAYER,
+                "norm_type %d: the library implements 'none' / 'input_norm' (0) and 'layer' (1); 'batch' (fused batch "
+                "norm with moving averages, agents/network/base_network.py:57-59) is not implemented", cfg->norm_type);
+    RLC_REQUIRE(cfg->separate_networks == 0 || cfg->separate_networks == 1, "separate_networks must be 0 or 1");
+    RLC_REQUIRE(!cfg->norm_type || (cfg->shared_l1_dim <= 1024 && cfg->actor_l2_dim <= 1024 && cfg->critic_l2_dim <= 1024),
+                "layer norm supports layer widths up to 1024");
     dv.d = rlc_make_dims(cfg->state_dim, cfg->action_dim, cfg->shared_l1_dim, cfg->actor_l2_dim,
-                         cfg->critic_l2_dim, cfg->batch_size, 0);
+                         cfg->critic_l2_dim, cfg->batch_size, 0, cfg->norm_type, cfg->separate_networks);
     if (rlc_mfma_supported(dv.d))
         dv.d = rlc_make_dims(cfg->state_dim, cfg->action_dim, cfg->shared_l1_dim, cfg->actor_l2_dim,
                              cfg->critic_l2_dim, cfg->batch_size, 1);
@@ -545,7 +551,7 @@ static int relayout(rlc_handle* h, int blocked) {
     if (h->dv.d.blocked == blocked) return 0;
     if (use_device(h)) return 1;
     const RlcDims od = h->dv.d;
-    const RlcDims nd = rlc_make_dims(od.S, od.A, od.H1, od.HA, od.HC, od.B, blocked);
+    const RlcDims nd = rlc_make_dims(od.S, od.A, od.H1, od.HA, od.HC, od.B, blocked, od.norm, od.sep);
     const size_t NA = h->dv.n_agents, PP = od.Ppad;
     std::vector<float> dev(NA * PP), compact(od.P), out(NA * PP);
     for (int which = 0; which < 6; which++) {

@@ -53,81 +53,44 @@ __host__ __device__ inline size_t rlc_widx(int blocked, int row, int col, int nc
     return blocked ? (size_t)rlc_blk_index(row, col, ncols) : (size_t)row * ncols + col;
 }
 
+#define RLC_DDPG_MAX_SEG 20
 struct RlcDims {
     int S, A, H1, HA, HC, B;
     int blocked;   // 1: Wa2 / Wc2 segments use the tile-blocked layout (MFMA kernel), 0: row-major (generic kernel)
+    int norm;      // 1: norm_type 'layer' -- tf.contrib layer_norm (beta, gamma) after every hidden fully_connected
+                   //    (agents/network/base_network.py:53-56); 0: 'none' / 'input_norm' (just the activation)
+    int sep;       // 1: separate actor / critic networks (agents/network/actor_network.py:73-96,
+                   //    critic_network.py:77-99): the critic has a first layer of its own; 0: the hydra network
     int arow0;     // device row of Wc2's first action row: H1 (row-major) or the next multiple of 16 (blocked), so
                    // that in the blocked layout the trunk rows H1..arow0-1 are zero padding and the k-loops of the
                    // forward GEMMs need no row mask
-    // DEVICE offsets of the ten tensors inside one agent's blob: each tensor starts on a 256-byte
-    // boundary so that rows can be fetched with 16-byte vector loads.  The ABI's compact blob
+    // DEVICE offsets of the tensors inside one agent's blob, variable creation order
+    //   W1 b1 [l1b l1g] Wa2 ba2 [l2b l2g] Wa3 ba3 | [Wc1 bc1 [lcb lcg]] Wc2 bc2 [l3b l3g] Wc3 bc3
+    // ([l..] with layer norm, [Wc1 ..] with separate networks; without them oWc1.. alias oW1..): each tensor starts
+    // on a 256-byte boundary so that rows can be fetched with 16-byte vector loads.  The ABI's compact blob
     // (rlc_ddpg_set_blob / get_blob) is packed/unpacked on the host with rlc_pack_blob / rlc_unpack_blob.
     int oW1, ob1, oWa2, oba2, oWa3, oba3, oWc2, obc2, oWc3, obc3;
+    int oL1b, oL1g, oL2b, oL2g, oL3b, oL3g, oWc1, obc1, oLcb, oLcg;
+    int ocritic0;  // device offset of the critic optimizer's own block (everything before it is the actor optimizer's)
+    int iWa2, iWc2;             // segment indices of the two matrices that can be tile-blocked
     int P;      // parameter count of the compact ABI blob
     int Pdev;   // extent of the device layout in use
     int Ppad;   // per-agent stride of every device blob (fits either layout, multiple of 64 floats)
-    int seg_len[10], seg_compact[10], seg_dev[10], seg_rows[10], seg_cols[10];
+    int nseg;
+    int seg_len[RLC_DDPG_MAX_SEG], seg_compact[RLC_DDPG_MAX_SEG], seg_dev[RLC_DDPG_MAX_SEG];
+    int seg_rows[RLC_DDPG_MAX_SEG], seg_cols[RLC_DDPG_MAX_SEG], seg_h[RLC_DDPG_MAX_SEG];
+    char seg_big[RLC_DDPG_MAX_SEG];
 };
 
-inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B, int blocked) {
-    RlcDims d;
-    d.S = S; d.A = A; d.H1 = H1; d.HA = HA; d.HC = HC; d.B = B;
-    d.blocked = blocked;
-    d.arow0 = blocked ? ((H1 + 15) & ~15) : H1;
-    const int rows[10] = {S, 1, H1, 1, HA, 1, H1 + A, 1, HC, 1};
-    const int cols[10] = {H1, H1, HA, HA, A, A, HC, HC, 1, 1};
-    int pc = 0, pd = 0, pmax = 0;
-    for (int i = 0; i < 10; i++) {
-        const int len = rows[i] * cols[i];
-        const bool big = i == 2 || i == 6;
-        const int blk = rlc_blk_floats(i == 6 ? ((H1 + 15) & ~15) + A : rows[i], cols[i]);
-        d.seg_len[i] = len; d.seg_rows[i] = rows[i]; d.seg_cols[i] = cols[i];
-        d.seg_compact[i] = pc;
-        d.seg_dev[i] = pd;
-        pc += len;
-        pd += (((big && blocked) ? blk : len) + 63) & ~63;
-        pmax += ((big ? (blk > len ? blk : len) : len) + 63) & ~63;
-    }
-    d.oW1 = d.seg_dev[0]; d.ob1 = d.seg_dev[1]; d.oWa2 = d.seg_dev[2]; d.oba2 = d.seg_dev[3];
-    d.oWa3 = d.seg_dev[4]; d.oba3 = d.seg_dev[5]; d.oWc2 = d.seg_dev[6]; d.obc2 = d.seg_dev[7];
-    d.oWc3 = d.seg_dev[8]; d.obc3 = d.seg_dev[9];
-    d.P = pc;
-    d.Pdev = pd;
-    d.Ppad = pmax;
-    return d;
-}
+template <class D> inline void rlc_layout_segs(D& d);
+template <class D> inline void rlc_pack_segs(const D& d, const float* compact, float* padded);
+template <class D> inline void rlc_unpack_segs(const D& d, const float* padded, float* compact);
+
+inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B, int blocked, int norm = 0, int sep = 0);
 
 // logical row -> device row of segment i (only Wc2's action rows move, see RlcDims::arow0)
 __host__ __device__ inline int rlc_dev_row(const RlcDims& d, int seg, int r) {
-    return (seg == 6 && r >= d.H1) ? d.arow0 + (r - d.H1) : r;
-}
-
-// compact row-major ABI blob <-> one agent's device blob (padded is Ppad floats, zero-filled by the caller)
-inline void rlc_pack_blob(const RlcDims& d, const float* compact, float* padded) {
-    for (int i = 0; i < 10; i++) {
-        const float* src = compact + d.seg_compact[i];
-        float* dst = padded + d.seg_dev[i];
-        if (d.blocked && (i == 2 || i == 6)) {
-            for (int r = 0; r < d.seg_rows[i]; r++)
-                for (int c = 0; c < d.seg_cols[i]; c++)
-                    dst[rlc_blk_index(rlc_dev_row(d, i, r), c, d.seg_cols[i])] = src[(size_t)r * d.seg_cols[i] + c];
-        } else {
-            for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
-        }
-    }
-}
-inline void rlc_unpack_blob(const RlcDims& d, const float* padded, float* compact) {
-    for (int i = 0; i < 10; i++) {
-        float* dst = compact + d.seg_compact[i];
-        const float* src = padded + d.seg_dev[i];
-        if (d.blocked && (i == 2 || i == 6)) {
-            for (int r = 0; r < d.seg_rows[i]; r++)
-                for (int c = 0; c < d.seg_cols[i]; c++)
-                    dst[(size_t)r * d.seg_cols[i] + c] = src[rlc_blk_index(rlc_dev_row(d, i, r), c, d.seg_cols[i])];
-        } else {
-            for (int k = 0; k < d.seg_len[i]; k++) dst[k] = src[k];
-        }
-    }
+    return (seg == d.iWc2 && r >= d.H1) ? d.arow0 + (r - d.H1) : r;
 }
 
 // Generic form of the two functions above for dims structs that carry a segment table (SAC, NAF): fields nseg,
@@ -184,6 +147,45 @@ inline void rlc_layout_segs(D& d) {
     }
     d.P = pc; d.Pdev = pd; d.Ppad = pmax;
 }
+
+inline RlcDims rlc_make_dims(int S, int A, int H1, int HA, int HC, int B, int blocked, int norm, int sep) {
+    RlcDims d;
+    d.S = S; d.A = A; d.H1 = H1; d.HA = HA; d.HC = HC; d.B = B;
+    d.blocked = blocked; d.norm = norm; d.sep = sep;
+    d.arow0 = blocked ? ((H1 + 15) & ~15) : H1;
+    int n = 0;
+    auto seg = [&](int r, int c, int big, int h) {
+        d.seg_rows[n] = r; d.seg_cols[n] = c; d.seg_big[n] = (char)big; d.seg_h[n] = h;
+        return n++;
+    };
+    auto vec = [&](int c) { return seg(1, c, 0, 1); };
+    const int iW1 = seg(S, H1, 0, S), ib1 = vec(H1);
+    const int iL1b = norm ? vec(H1) : -1, iL1g = norm ? vec(H1) : -1;
+    d.iWa2 = seg(H1, HA, 1, H1);
+    const int iba2 = vec(HA);
+    const int iL2b = norm ? vec(HA) : -1, iL2g = norm ? vec(HA) : -1;
+    const int iWa3 = seg(HA, A, 0, HA), iba3 = vec(A);
+    const int icrit = n;
+    const int iWc1 = sep ? seg(S, H1, 0, S) : iW1, ibc1 = sep ? vec(H1) : ib1;
+    const int iLcb = (sep && norm) ? vec(H1) : iL1b, iLcg = (sep && norm) ? vec(H1) : iL1g;
+    d.iWc2 = seg(H1 + A, HC, 1, H1);
+    const int ibc2 = vec(HC);
+    const int iL3b = norm ? vec(HC) : -1, iL3g = norm ? vec(HC) : -1;
+    const int iWc3 = seg(HC, 1, 0, HC), ibc3 = vec(1);
+    d.nseg = n;
+    rlc_layout_segs(d);
+    auto at = [&](int i) { return i >= 0 ? d.seg_dev[i] : 0; };
+    d.oW1 = at(iW1); d.ob1 = at(ib1); d.oWa2 = at(d.iWa2); d.oba2 = at(iba2); d.oWa3 = at(iWa3); d.oba3 = at(iba3);
+    d.oWc2 = at(d.iWc2); d.obc2 = at(ibc2); d.oWc3 = at(iWc3); d.obc3 = at(ibc3);
+    d.oL1b = at(iL1b); d.oL1g = at(iL1g); d.oL2b = at(iL2b); d.oL2g = at(iL2g); d.oL3b = at(iL3b); d.oL3g = at(iL3g);
+    d.oWc1 = at(iWc1); d.obc1 = at(ibc1); d.oLcb = at(iLcb); d.oLcg = at(iLcg);
+    d.ocritic0 = d.seg_dev[icrit];
+    return d;
+}
+
+// compact row-major ABI blob <-> one agent's device blob (padded is Ppad floats, zero-filled by the caller)
+inline void rlc_pack_blob(const RlcDims& d, const float* compact, float* padded) { rlc_pack_segs(d, compact, padded); }
+inline void rlc_unpack_blob(const RlcDims& d, const float* padded, float* compact) { rlc_unpack_segs(d, padded, compact); }
 
 // Replay ring of ONE agent lives at agent*cap inside each SoA array.  Logical index 0 = oldest.
 struct RlcRingMeta {
@@ -400,11 +402,34 @@ __device__ __forceinline__ RlcWCol rlc_wcol(const float* W, int blocked, int n, 
     return w;
 }
 
+// One row z[0..N) (LDS or global) -> relu(tf.contrib layer_norm(z)) in place, by the whole workgroup (B = 1 acting
+// paths).  red: >= 34 floats of LDS.  Biased variance over the features, eps 1e-12 (base_network.py:53-56).
+__device__ inline void rlc_row_layernorm_relu(float* z, int N, const float* beta, const float* gamma, float* red) {
+    const int tid = threadIdx.x, nthr = blockDim.x, nw = (nthr + 63) >> 6;
+    auto block_sum = [&](float v) {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        float t = 0.0f;
+        for (int w = 0; w < nw; w++) t += red[w];
+        return t;
+    };
+    float s = 0.0f;
+    for (int n = tid; n < N; n += nthr) s += z[n];
+    const float mean = block_sum(s) / (float)N;
+    float q = 0.0f;
+    for (int n = tid; n < N; n += nthr) { const float c = z[n] - mean; q += c * c; }
+    const float rs = 1.0f / sqrtf(block_sum(q) / (float)N + 1e-12f);
+    for (int n = tid; n < N; n += nthr) z[n] = fmaxf((z[n] - mean) * rs * gamma[n] + beta[n], 0.0f);
+    __syncthreads();
+}
+
 // h_out[n] = relu(bias[n] + sum_k h_in[k] W[k][n]) for one row (B = 1 acting paths), W in either device layout.
 // One thread per output unit, k ascending in one accumulator; the weight column is fetched KC rows at a time so
 // that KC loads are in flight per thread instead of one dependent chain.  No barrier inside.
 __device__ inline void rlc_hidden_forward_row(const float* W, int blocked, const float* bias, const float* h_in, int K,
-                                              int N, float* h_out) {
+                                              int N, float* h_out, bool relu = true) {
     constexpr int KC = 16;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const RlcWCol wcol = rlc_wcol(W, blocked, n, N);
@@ -419,7 +444,7 @@ __device__ inline void rlc_hidden_forward_row(const float* W, int blocked, const
             for (int i = 0; i < KC; i++) acc += h_in[k0 + i] * w[i];
         }
         for (; k0 < K; k0++) acc += h_in[k0] * *wcol.at(k0);
-        h_out[n] = fmaxf(acc + bias[n], 0.0f);
+        h_out[n] = relu ? fmaxf(acc + bias[n], 0.0f) : acc + bias[n];
     }
 }
 

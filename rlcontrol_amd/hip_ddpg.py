@@ -14,30 +14,42 @@ from ._lib import check, dptr, f64, fptr, iptr
 from .hip_pop import Population
 
 
-def param_layout(S, A, H1, HA, HC):
-    """name -> (offset, shape), creation order of hydra_ddpg_network.py:100-140."""
+NORM_TYPES = {"none": 0, "input_norm": 0, "layer": 1}
+
+
+def param_layout(S, A, H1, HA, HC, norm_type="input_norm", separate_networks=False):
+    """name -> (offset, shape), variable creation order of hydra_ddpg_network.py:100-140; with norm_type 'layer' every
+    hidden layer is followed by its LayerNorm beta then gamma (base_network.py:53-56), with separate networks
+    (actor_network.py:73-96, critic_network.py:77-99) the critic block starts with a first layer of its own."""
+    ln = lambda tag, n: [(tag + "b", (n,)), (tag + "g", (n,))] if NORM_TYPES[norm_type] else []
+    items = [("W1", (S, H1)), ("b1", (H1,))] + ln("l1", H1) + [("Wa2", (H1, HA)), ("ba2", (HA,))] + ln("l2", HA) + \
+            [("Wa3", (HA, A)), ("ba3", (A,))]
+    if separate_networks:
+        items += [("Wc1", (S, H1)), ("bc1", (H1,))] + ln("lc", H1)
+    items += [("Wc2", (H1 + A, HC)), ("bc2", (HC,))] + ln("l3", HC) + [("Wc3", (HC, 1)), ("bc3", (1,))]
     out = OrderedDict()
     p = 0
-    for name, shp in (("W1", (S, H1)), ("b1", (H1,)), ("Wa2", (H1, HA)), ("ba2", (HA,)),
-                      ("Wa3", (HA, A)), ("ba3", (A,)), ("Wc2", (H1 + A, HC)), ("bc2", (HC,)),
-                      ("Wc3", (HC, 1)), ("bc3", (1,))):
+    for name, shp in items:
         out[name] = (p, shp)
         p += int(np.prod(shp))
     return out, p
 
 
-def init_params(S, A, H1, HA, HC, seed):
+def init_params(S, A, H1, HA, HC, seed, norm_type="input_norm", separate_networks=False):
     """Initial weights with the reference's initialiser families (hydra_ddpg_network.py:101-140):
     hidden W and b ~ U(+-sqrt(3/fan_in)) (variance_scaling_initializer(factor=1, FAN_IN, uniform);
-    for a 1-D bias [n] TF takes fan_in = n), output-layer W, b ~ U(+-3e-3).  TensorFlow's own
+    for a 1-D bias [n] TF takes fan_in = n), output-layer W, b ~ U(+-3e-3); LayerNorm beta 0, gamma 1.  TensorFlow's own
     Philox stream under tf.set_random_seed(seed) (agents/DDPG.py:21) cannot be reproduced without
     TensorFlow, so the draws come from numpy RandomState(seed): same distributions, different
     numbers ("parity unpinned")."""
     rng = np.random.RandomState(seed)
-    lay, P = param_layout(S, A, H1, HA, HC)
+    lay, P = param_layout(S, A, H1, HA, HC, norm_type, separate_networks)
     theta = np.zeros(P, np.float32)
     for name, (off, shp) in lay.items():
         n = int(np.prod(shp))
+        if name[0] == "l":
+            theta[off:off + n] = 1.0 if name.endswith("g") else 0.0
+            continue
         lim = 3e-3 if name in ("Wa3", "ba3", "Wc3", "bc3") else np.sqrt(3.0 / shp[0])
         theta[off:off + n] = rng.uniform(-lim, lim, n).astype(np.float32)
     return theta
@@ -50,10 +62,15 @@ class DDPGPopulation(Population):
 
     def __init__(self, n_agents, state_dim, action_dim, shared_l1_dim, actor_l2_dim, critic_l2_dim, batch_size,
                  buffer_size, tau, state_min, state_max, action_min, action_max, actor_lr, critic_lr, seeds,
-                 clip_state=True, ou_theta=0.15, ou_mu=0.0, ou_sigma=0.2, device=0):
+                 clip_state=True, ou_theta=0.15, ou_mu=0.0, ou_sigma=0.2, device=0, norm_type="input_norm",
+                 separate_networks=False):
         self._init_base(n_agents, state_dim, action_dim, batch_size)
         self.H1, self.HA, self.HC = int(shared_l1_dim), int(actor_l2_dim), int(critic_l2_dim)
-        self.layout, self.P = param_layout(self.S, self.A, self.H1, self.HA, self.HC)
+        if norm_type not in NORM_TYPES:
+            raise ValueError("norm_type %r: the HIP path implements 'none', 'input_norm' and 'layer' (the reference's "
+                             "'batch', base_network.py:57-59, is not implemented)" % (norm_type,))
+        self.norm_type, self.separate_networks = norm_type, bool(separate_networks)
+        self.layout, self.P = param_layout(self.S, self.A, self.H1, self.HA, self.HC, norm_type, separate_networks)
         bc = lambda v, n: np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32).reshape(-1), (n,)))
         self._keep = dict(
             smin=bc(state_min, self.S), smax=bc(state_max, self.S), amin=bc(action_min, self.A),
@@ -67,6 +84,8 @@ class DDPGPopulation(Population):
         cfg.batch_size = self.B
         cfg.buffer_size = int(buffer_size)
         cfg.clip_state = 1 if clip_state else 0
+        cfg.norm_type = NORM_TYPES[norm_type]
+        cfg.separate_networks = 1 if separate_networks else 0
         cfg.tau = float(tau)
         cfg.state_min, cfg.state_max = fptr(self._keep["smin"]), fptr(self._keep["smax"])
         cfg.action_min, cfg.action_max = fptr(self._keep["amin"]), fptr(self._keep["amax"])

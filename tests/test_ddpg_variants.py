@@ -99,3 +99,126 @@ def test_layer_norm_statistics_follow_tf_contrib():
     h2 = np.maximum((z2 - z2.mean(1, keepdims=True)) / np.sqrt(z2.var(1, keepdims=True) + 1e-12), 0.0)
     mu = np.tanh(h2 @ th[lay["Wa3"][0]:lay["Wa3"][0] + 16].reshape(16, 1) + th[lay["ba3"][0]]) * 2.0
     assert _rel(o.act(s), mu) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ GPU
+def _pop(dims, B, norm, sep, n_agents=1, cap=512):
+    from rlcontrol_amd.hip_ddpg import DDPGPopulation
+    S, A, H1, HA, HC = dims
+    smin, smax, amax = _bounds(S, A)
+    return DDPGPopulation(n_agents, S, A, H1, HA, HC, B, cap, 0.01, smin, smax, -amax, amax, 1e-3, 1e-2,
+                          seeds=list(range(7, 7 + n_agents)), norm_type="layer" if norm else "input_norm",
+                          separate_networks=sep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("norm,sep", VARIANTS)
+@pytest.mark.parametrize("dims,B", SHAPES)
+def test_hip_variant_update_matches_oracle(hip_lib, dims, B, norm, sep):
+    d = VDims(*dims, norm=norm, separate=sep)
+    th = init_params(d, 2)
+    rng = np.random.RandomState(1)
+    lay, P = d.layout()
+    for n, (off, shp) in lay.items():
+        if n[0] == "l":
+            k = int(np.prod(shp))
+            th[off:off + k] += rng.uniform(-0.3, 0.3, k).astype(np.float32)
+    smin, smax, amax = _bounds(dims[0], dims[1])
+    pop = _pop(dims, B, norm, sep)
+    assert pop.P == P and pop.kernel_in_use() == "generic"            # the variants run on the any-shape kernel
+    from rlcontrol_amd.hip_ddpg import param_layout
+    assert list(param_layout(*dims, "layer" if norm else "input_norm", sep)[0]) == list(lay)
+    pop.enable_grad_taps(True)
+    pop.set_params(0, th)
+    o = DDPGVariantOracle(d, th, 1e-3, 1e-2, 0.01, smin, smax, amax)
+    for it in range(3):
+        s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+        pop.update_batch(0, s, a, s2, r, g)
+        t = o.update(s, a, s2, r, g, taps=True)
+        tol = 1e-5 if it == 0 else 2e-4
+        for k in ("q", "y", "a_out", "dqda"):
+            assert _rel(pop.last_tap(0, k), t[k]) < tol, (it, k)
+        if it == 0:
+            for tag in ("grads_c", "grads_a"):
+                got = pop.last_tap(0, tag)
+                for n, (off, shp) in lay.items():
+                    k = int(np.prod(shp))
+                    if np.max(np.abs(t[tag][off:off + k])) > 0:
+                        assert _rel(got[off:off + k], t[tag][off:off + k]) < 3e-5, (tag, n)
+            assert _rel(pop.get_blob(0, "theta"), o.theta) < 1e-5
+            assert _rel(pop.get_blob(0, "theta_target"), o.theta_t) < 1e-5
+    st = rng.uniform(-2, 2, (1, dims[0]))
+    assert _rel(pop.act(st), o.act(st)) < 1e-5                        # acting path (B = 1) through the layer norms
+    pop.close()
+
+
+@pytest.mark.gpu
+def test_hip_variant_replay_path_and_kernel_guard(hip_lib):
+    """fused sample + gather + update on the replay with layer norm; the MFMA kernel and the device loop refuse"""
+    from rlcontrol_amd._lib import RlcError
+    dims, B, N = (3, 1, 200, 200, 200), 100, 512
+    d = VDims(*dims, norm=True)
+    smin, smax, amax = _bounds(3, 1)
+    pop = _pop(dims, B, True, False, n_agents=2, cap=N)
+    rng = np.random.RandomState(3)
+    data = (rng.uniform(-2, 2, (N, 3)), rng.uniform(-1, 1, (N, 1)), rng.uniform(-16, 0, N), rng.uniform(-2, 2, (N, 3)),
+            np.full(N, 0.99))
+    ths = [init_params(d, 30 + i) for i in range(2)]
+    oracles = []
+    for i in range(2):
+        pop.set_params(i, ths[i])
+        pop.replay_add_batch(i, *data)
+        oracles.append(DDPGVariantOracle(d, ths[i], 1e-3, 1e-2, 0.01, smin, smax, amax))
+    idx = np.stack([rng.choice(N, B, replace=False) for _ in range(4)]).reshape(2, 2, B).astype(np.int64)
+    pop.update(2, host_indices=idx)
+    for i in range(2):
+        for k in range(2):
+            j = idx[i, k]
+            t = oracles[i].update(data[0][j], data[1][j], data[3][j], data[2][j], data[4][j], taps=True)
+        for name in ("q", "y", "dqda"):
+            assert _rel(pop.last_tap(i, name), t[name]) < 2e-4, (i, name)
+    with pytest.raises(RlcError):
+        pop.set_kernel("mfma")
+    pop.update(3)                                                      # device sampler path
+    assert np.all(np.isfinite(pop.get_blob(1, "theta")))
+    pop.close()
+
+
+@pytest.mark.gpu
+def test_dropin_agent_accepts_layer_norm_and_rejects_batch_norm(hip_lib):
+    from rlcontrol_amd.utils.config import Config
+    from rlcontrol_amd.utils.main_utils import create_agent
+    from rlcontrol_amd.environments.environments import create_environment
+    env = create_environment({"environment": "Pendulum-v0", "TotalMilSteps": 0.001, "EpisodeSteps": -1,
+                              "EvalIntervalMilSteps": 0.0005, "EvalEpisodes": 2})
+
+    def cfg(norm):
+        c = Config()
+        c.merge_config({"env_name": env.name, "state_dim": env.state_dim, "state_min": env.state_min,
+                        "state_max": env.state_max, "action_dim": env.action_dim, "action_min": env.action_min,
+                        "action_max": env.action_max, "norm_type": norm, "exploration_policy": "ou_noise",
+                        "shared_l1_dim": 64, "actor_l2_dim": 64, "critic_l2_dim": 64, "actor_lr": 1e-3, "critic_lr": 1e-2,
+                        "buffer_size": 2000, "writer": None, "write_log": False, "write_plot": False, "random_seed": 0})
+        return c
+    agent = create_agent("DDPG", cfg("layer"))
+    env.set_random_seed(0)
+    obs = env.reset()
+    agent.reset()
+    a = agent.start(obs, True)
+    for t in range(60):
+        obs_n, r, done, _ = env.step(a)
+        agent.update(obs, obs_n, float(r), a, done, False)
+        a = agent.step(obs_n, True)
+        obs = obs_n
+        assert a.shape == (1,) and abs(a[0]) <= 2.0
+    with pytest.raises(ValueError):
+        create_agent("DDPG", cfg("batch"))
+    for name, extra in (("SoftActorCritic", {"actor_l1_dim": 16, "actor_l2_dim": 16, "critic_l1_dim": 16, "critic_l2_dim": 16,
+                                            "pi_lr": 1e-3, "qf_vf_lr": 1e-3, "entropy_scale": 0.1, "sample_for_eval": "False",
+                                            "use_true_q": "False", "exploration_policy": "none"}),
+                        ("NAF", {"l1_dim": 16, "l2_dim": 16, "noise_scale": 0.3, "learning_rate": 1e-3,
+                                 "exploration_policy": "none"})):
+        c = cfg("layer")
+        c.merge_config(extra)
+        with pytest.raises(ValueError):
+            create_agent(name, c)
