@@ -164,12 +164,14 @@ __device__ inline void blk_dense(const float* X, int ldx, int K, const float* E,
     }
 }
 
-// dX[b,k] = (Hk[b,k] > 0) ? sum_n dY[b,n] W[k,n] : 0      (W[k][n] rows k < K only)
-__device__ inline void blk_dense_bwd_input(const float* dY, int N, const float* W, const float* Hk, int K, float* dX,
-                                    int B) {
-    if ((N & 3) == 0 && (K & 3) == 0 && al16(dY) && al16(W)) {
-        // this variant always masks by Hk > 0 (Hk is never null here)
-        blk_bwd_input_tile4(dY, N, N, W, Hk, K, dX, B, false);
+// dX[b,k] (+)= sum_n dY[b,n] W[k,n] (W[k][n] rows k < K only), masked by (Hk[b,k] > 0) unless Hk is null; lddy = leading
+// dimension of dY (heads that write into a strided slot array); accumulate = add into dX.  One implementation for
+// every caller: the 4 x 4 register-tile fast path when shapes and alignment allow, element-wise otherwise (same
+// summation order over n).
+__device__ inline void blk_dense_bwd_input_ld(const float* dY, int lddy, int N, const float* W, const float* Hk, int K,
+                                              float* dX, int B, bool accumulate) {
+    if ((N & 3) == 0 && (K & 3) == 0 && (lddy & 3) == 0 && al16(dY) && al16(W)) {
+        blk_bwd_input_tile4(dY, lddy, N, W, Hk, K, dX, B, accumulate);
         return;
     }
     const int rb = (B + kRows - 1) / kRows;
@@ -184,13 +186,26 @@ __device__ inline void blk_dense_bwd_input(const float* dY, int N, const float* 
 #pragma unroll
             for (int i = 0; i < kRows; i++) {
                 const int b = min(b0 + i, B - 1);
-                acc[i] += dY[(size_t)b * N + n] * w;
+                acc[i] += dY[(size_t)b * lddy + n] * w;
             }
         }
 #pragma unroll
         for (int i = 0; i < kRows; i++)
-            if (b0 + i < B) dX[(size_t)(b0 + i) * K + k] = Hk[(size_t)(b0 + i) * K + k] > 0.0f ? acc[i] : 0.0f;
+            if (b0 + i < B) {
+                const size_t p = (size_t)(b0 + i) * K + k;
+                const float v = (Hk == nullptr || Hk[p] > 0.0f) ? acc[i] : 0.0f;
+                dX[p] = accumulate ? dX[p] + v : v;
+            }
     }
+}
+// dense dY, always masked by Hk > 0, overwrite
+__device__ inline void blk_dense_bwd_input(const float* dY, int N, const float* W, const float* Hk, int K, float* dX, int B) {
+    blk_dense_bwd_input_ld(dY, N, N, W, Hk, K, dX, B, false);
+}
+// dense dY, optional mask, optional accumulation
+__device__ inline void blk_dense_bwd_input_ex(const float* dY, int N, const float* W, const float* Hk, int K, float* dX,
+                                              int B, bool accumulate) {
+    blk_dense_bwd_input_ld(dY, N, N, W, Hk, K, dX, B, accumulate);
 }
 
 // ---- tf.contrib.layers.layer_norm (agents/network/base_network.py:53-56) on the rows of a [B, N] activation ----
@@ -339,70 +354,7 @@ __device__ inline void blk_dense_grad_adam(const float* X, int ldx, int K, const
 }
 
 
-// dX[b,k] (+)= sum_n dY[b,n] W[k,n], optionally masked by (Hk[b,k] > 0); accumulate = add into dX
-__device__ inline void blk_dense_bwd_input_ex(const float* dY, int N, const float* W, const float* Hk, int K, float* dX,
-                                              int B, bool accumulate) {
-    if ((N & 3) == 0 && (K & 3) == 0 && al16(dY) && al16(W)) {
-        blk_bwd_input_tile4(dY, N, N, W, Hk, K, dX, B, accumulate);
-        return;
-    }
-    const int rb = (B + kRows - 1) / kRows;
-    for (int it = threadIdx.x; it < rb * K; it += kThreads) {
-        const int k = it % K;
-        const int b0 = (it / K) * kRows;
-        float acc[kRows];
-#pragma unroll
-        for (int i = 0; i < kRows; i++) acc[i] = 0.0f;
-        for (int n = 0; n < N; n++) {
-            const float w = W[(size_t)k * N + n];
-#pragma unroll
-            for (int i = 0; i < kRows; i++) {
-                const int b = min(b0 + i, B - 1);
-                acc[i] += dY[(size_t)b * N + n] * w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kRows; i++)
-            if (b0 + i < B) {
-                const size_t p = (size_t)(b0 + i) * K + k;
-                const float v = (Hk == nullptr || Hk[p] > 0.0f) ? acc[i] : 0.0f;
-                dX[p] = accumulate ? dX[p] + v : v;
-            }
-    }
-}
-
-// ---- variants with an explicit leading dimension of dY (heads that write into a strided slot array) ----
-__device__ inline void blk_dense_bwd_input_ld(const float* dY, int lddy, int N, const float* W, const float* Hk, int K,
-                                              float* dX, int B, bool accumulate) {
-    if ((N & 3) == 0 && (K & 3) == 0 && (lddy & 3) == 0 && al16(dY) && al16(W)) {
-        blk_bwd_input_tile4(dY, lddy, N, W, Hk, K, dX, B, accumulate);
-        return;
-    }
-    const int rb = (B + kRows - 1) / kRows;
-    for (int it = threadIdx.x; it < rb * K; it += kThreads) {
-        const int k = it % K;
-        const int b0 = (it / K) * kRows;
-        float acc[kRows];
-#pragma unroll
-        for (int i = 0; i < kRows; i++) acc[i] = 0.0f;
-        for (int n = 0; n < N; n++) {
-            const float w = W[(size_t)k * N + n];
-#pragma unroll
-            for (int i = 0; i < kRows; i++) {
-                const int b = min(b0 + i, B - 1);
-                acc[i] += dY[(size_t)b * lddy + n] * w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < kRows; i++)
-            if (b0 + i < B) {
-                const size_t p = (size_t)(b0 + i) * K + k;
-                const float v = (Hk == nullptr || Hk[p] > 0.0f) ? acc[i] : 0.0f;
-                dX[p] = accumulate ? dX[p] + v : v;
-            }
-    }
-}
-
+// ---- variant with an explicit leading dimension of dY (heads that write into a strided slot array) ----
 __device__ inline void blk_dense_grad_adam_ld(const float* X, int ldx, int K, const float* dY, int lddy, int N, int B,
                                               const AdamCtx& c, int oW, int ob) {
     const int rows = K + 1;   // last "row" is the bias

@@ -87,3 +87,26 @@ def test_rollout_oracle_bookkeeping_equals_host_experiment():
     assert len(agent.replay) == len(orc.replay) == 130 - 4          # truncated 30th steps are not stored (Q7)
     assert agent.n_updates == orc.n_updates                          # learn() gate (Q12)
     assert all(t[4] == 0.99 for t in orc.replay)                     # Pendulum never stores a terminal
+
+
+def test_sampler_is_jointly_uniform_over_ordered_tuples_in_both_regimes():
+    """not only the marginals.  The sparse regime (3k < n: every thread draws, duplicates of
+    lower-numbered threads are redrawn until none remain) is equivariant under permutations of the index values, and the
+    distinct ordered k-tuples are one orbit of that group -- so every tuple must be equally likely, as for sequential
+    sampling without replacement (sample_n_k, custom_collections.py:107-131).  Chi-square over ALL ordered triples, for
+    the sparse regime (n = 10) and the dense Fisher-Yates regime (n = 7).  oracle/philox.py is bit-identical to the
+    device sampler (tests/test_gpu_replay.py, tests/test_gpu_rollout.py)."""
+    import itertools
+    from oracle import philox
+    for n, calls in ((10, 72000), (7, 31500)):
+        k = 3
+        cells = {t: 0 for t in itertools.permutations(range(n), k)}
+        for call in range(calls):
+            t = tuple(int(v) for v in philox.sample_distinct(n, k, 12345, call))
+            assert len(set(t)) == k
+            cells[t] += 1
+        exp = calls / float(len(cells))
+        chi2 = sum((c - exp) ** 2 / exp for c in cells.values())
+        dof = len(cells) - 1
+        assert chi2 < dof + 5.0 * np.sqrt(2.0 * dof), (n, chi2, dof)       # 5 sigma
+        assert min(cells.values()) > 0.5 * exp
