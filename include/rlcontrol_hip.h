@@ -197,6 +197,71 @@ int rlc_sac_enable_grad_taps(rlc_sac* h, int32_t on);
 int rlc_sac_set_kernel(rlc_sac* h, int32_t variant);
 int rlc_sac_get_kernel(const rlc_sac* h, int32_t* variant_in_use);
 
+/* ============================== ReverseKL / ForwardKL ==============================================
+ * Mirrors what ReverseKL_Network_Manager / ReverseKLNetwork (agents/ReverseKL.py:13-29,
+ * agents/network/reversekl_network.py:23-76) and their ForwardKL twins (agents/ForwardKL.py,
+ * agents/network/forwardkl_network.py:23-106) read from Config; jsonfiles/agent/reverse_kl.json, forward_kl.json.
+ * The reference builds these two agents on torch.nn / torch.optim.Adam; this entry point replaces
+ * network.update_network + network.update_target_network (agents/ReverseKL.py:83-93) and sample_action / predict_action.
+ * Parameter blob (P floats), weights stored [in][out] (the transpose of nn.Linear.weight), module order
+ * pi_net, q_net, v_net (reversekl_network.py:47-50):
+ *   pi: W1[S][L1a] b1 W2[L1a][L2a] b2 Wm[L2a][A] bm Ws[L2a][A] bs | q: W1[S+A][L1c] b1 W2[L1c][L2c] b2 W3[L2c] b3 |
+ *   v: W1[S][L1c] b1 W2[L1c][L2c] b2 W3[L2c] b3.      blob selector: 0 theta, 1 target (only the v block is live:
+ *   target_v_net), 2 Adam exp_avg, 3 Adam exp_avg_sq.
+ * action_dim must be 1: the action integral is the Clenshaw-Curtis line rule of the action_dim == 1 branch
+ * (reversekl_network.py:64-76); the sparse-grid branch for action_dim > 1 (l_param) is not implemented. */
+#define RLC_KL_REVERSE 1
+#define RLC_KL_FORWARD 2
+#define RLC_KL_OPTIM_INTG 0        /* config.optim_type 'intg'      (reverse: soft RKL; forward: the only one implemented there) */
+#define RLC_KL_OPTIM_HARD_INTG 1   /* 'hard_intg'  (reverse only, reversekl_network.py:196-207) */
+#define RLC_KL_OPTIM_LL 2          /* 'll'         (reverse only, :167-171) */
+#define RLC_KL_OPTIM_HARD_LL 3     /* 'hard_ll'    (reverse only, :173-175) */
+#define RLC_KL_Q_NON_SAC 0         /* config.q_update_type 'non_sac': V target (r - alpha*logp) + gamma*V'(s') (:157-158) */
+#define RLC_KL_Q_SAC 1             /* 'sac': V target Q(s, a_new) - alpha*logp (:154-155) */
+typedef struct rlc_kl_config {
+    int32_t device, n_agents, state_dim, action_dim;
+    int32_t actor_l1_dim, actor_l2_dim, critic_l1_dim, critic_l2_dim;   /* jsonfiles/agent/reverse_kl.json:8-11 */
+    int32_t batch_size;
+    int32_t kind;            /* RLC_KL_REVERSE / RLC_KL_FORWARD */
+    int32_t optim_type;      /* RLC_KL_OPTIM_* */
+    int32_t q_update_type;   /* RLC_KL_Q_* */
+    int32_t n_nodes;         /* quadrature nodes kept: N_param - 2 (the end points are cut, reversekl_network.py:70-72) */
+    int32_t reserved0;
+    int64_t buffer_size;
+    float tau;
+    float action_max0;               /* action_max[0]: scale of tanh (reversekl_network.py:47) */
+    const float* node_actions;       /* [n_nodes] scheme.points[1:-1] * action_max, fp32 (self.intgrl_actions) */
+    const float* node_weights;       /* [n_nodes] scheme.weights[1:-1], fp32 (self.intgrl_weights) */
+    const float* pi_lr;              /* [n_agents] */
+    const float* qf_vf_lr;           /* [n_agents] */
+    const float* entropy_scale;      /* [n_agents] */
+    const uint64_t* seed;            /* [n_agents] Philox keys (sampler, eps) */
+} rlc_kl_config;
+typedef rlc_handle rlc_kl;
+
+int rlc_kl_create(const rlc_kl_config* cfg, rlc_kl** out);
+int rlc_kl_param_count(const rlc_kl* h, int64_t* out_p);
+int rlc_kl_set_blob(rlc_kl* h, int32_t agent, int32_t which, const float* src, int64_t n);
+int rlc_kl_get_blob(rlc_kl* h, int32_t agent, int32_t which, float* dst, int64_t n);
+int rlc_kl_set_step(rlc_kl* h, int32_t agent, int32_t step);   /* state['step'] of the three torch optimizers (equal) */
+int rlc_kl_get_step(rlc_kl* h, int32_t agent, int32_t* step);
+int rlc_kl_init_target(rlc_kl* h, int32_t agent);              /* reversekl_network.py:52-54 */
+/* predict_action (sample = 0: tanh(mean)*action_max[0], :120-128) / sample_action (sample = 1, :111-118).
+ * eps: [n][A] N(0,1) draws standing in for normal.sample(), or NULL -> device Philox. */
+int rlc_kl_act(rlc_kl* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
+               float* out_actions);
+/* BaseAgent.learn for every agent: sample_batch + update_network + update_target_network.
+ * host_indices as in rlc_ddpg_update; eps [n_agents][n_updates][batch][A] or NULL. */
+int rlc_kl_update(rlc_kl* h, int32_t n_updates, const int64_t* host_indices, const float* eps);
+/* *_Network_Manager.update_network on a caller-supplied minibatch (one agent); eps [batch][A] or NULL */
+int rlc_kl_update_batch(rlc_kl* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+                        const double* next_states, const double* rewards, const double* gammas, const float* eps);
+/* taps of the last update: 0 q_val, 1 v_val, 2 log_prob, 3 new_q_val (n = batch); 4 {policy_loss, q_value_loss,
+ * value_loss} (n = 3); 5 gradient blob (n = P, needs rlc_kl_enable_grad_taps); 6 intgrl_q_val (n = batch * n_nodes,
+ * the integral updates only) */
+int rlc_kl_last_tap(rlc_kl* h, int32_t agent, int32_t which, float* dst, int64_t n);
+int rlc_kl_enable_grad_taps(rlc_kl* h, int32_t on);
+
 
 /* ===================================== NAF =========================================================
  * Mirrors what NAF_Network_Manager.__init__ / NAF_Network.__init__ read from Config (agents/NAF.py:11-21,

@@ -1,0 +1,238 @@
+"""CPU oracle of the ReverseKL / ForwardKL agents -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+The reference implements these two agents in PyTorch (agents/network/reversekl_network.py,
+agents/network/forwardkl_network.py); PyTorch is installed here, so this restatement runs the same tensor ops in fp32
+and lets autograd form the gradients -- which makes it an independent check of the hand-derived backward pass of
+kl_generic.hip.  It is written functionally over ONE flat parameter blob (the C ABI's layout) instead of nn.Modules.
+
+Reference lines restated
+  networks         reversekl_network.py:238-330  (ValueNetwork, SoftQNetwork [state,action] concatenated at the INPUT,
+                   PolicyNetwork with log_std clamped to [-20, 2])
+  evaluate         reversekl_network.py:332-357  (z ~ Normal(mean, std) without reparameterisation gradient,
+                   log_prob - log(1 - tanh(z)^2 + 1e-6), actions scaled by action_max[0])
+  get_logprob      reversekl_network.py:360-381  (atanh of the normalised node, same squash correction)
+  update (reverse) reversekl_network.py:130-218  (optim_type ll / hard_ll / intg / hard_intg; q_update_type sac / non_sac)
+  update (forward) forwardkl_network.py:123-207  (optim_type intg: Boltzmann weights exp(Q/alpha - max) / Z)
+  target update    reversekl_network.py:220-225  (V network only, target*(1-tau) + param*tau)
+  Adam             torch 1.7.1 torch/optim/_functional.py adam(): mul_/add_ moments, denom = sqrt(v)/sqrt(1-b2^t) + eps,
+                   step_size = lr/(1-b1^t)  (requirements.txt pins torch==1.7.1)
+Parity status: "parity unpinned" -- the reference holds no fixture for these agents and cannot be imported here
+(quadpy and gym are absent), so nothing produced BY the reference anchors this file.  What anchors it: the torch ops
+are the reference's own third-party arithmetic; the explicit Adam below is checked against torch.optim.Adam
+(tests/test_kl.py); the quadrature rule is checked against the product's independent closed-form implementation and
+against polynomial exactness.
+The minibatch noise: the reference draws z with torch's global generator (normal.sample()); here eps ~ N(0,1) is an
+input and z = mean + std * eps, the expression torch.normal(mean, std) evaluates.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+LOG_STD_MIN, LOG_STD_MAX = -20.0, 2.0
+KINDS = ("reverse", "forward")
+OPTIM_TYPES = ("intg", "hard_intg", "ll", "hard_ll")
+Q_UPDATE_TYPES = ("non_sac", "sac")
+
+
+def cc_rule(n_points):
+    """Clenshaw-Curtis rule by Waldvogel's FFT construction (BIT Numer. Math. 46, 2006) -- deliberately a different
+    algorithm from rlcontrol_amd/utils/quadrature.py, so that the two check each other."""
+    n = int(n_points) - 1
+    pts = -np.cos(np.pi * np.arange(n + 1) / n)
+    N = np.arange(1, n, 2)
+    l = len(N)
+    m = n - l
+    v0 = np.concatenate([2.0 / N / (N - 2), [1.0 / N[-1]], np.zeros(m)])
+    v2 = -v0[:-1] - v0[:0:-1]
+    g0 = -np.ones(n)
+    g0[l] += n
+    g0[m] += n
+    g = g0 / (n ** 2 - 1 + (n % 2))
+    w = np.fft.ifft(v2 + g).real
+    return pts, np.concatenate([w, w[:1]])
+
+
+class KlDims(object):
+    """(state_dim, action_dim, actor_l1_dim, actor_l2_dim, critic_l1_dim, critic_l2_dim); weights are [in, out]."""
+
+    def __init__(self, S, A, L1A, L2A, L1C, L2C):
+        self.t = (int(S), int(A), int(L1A), int(L2A), int(L1C), int(L2C))
+
+    def layout(self):
+        S, A, L1A, L2A, L1C, L2C = self.t
+        out, p = OrderedDict(), 0
+        for name, shp in (("pW1", (S, L1A)), ("pb1", (L1A,)), ("pW2", (L1A, L2A)), ("pb2", (L2A,)),
+                          ("pWm", (L2A, A)), ("pbm", (A,)), ("pWs", (L2A, A)), ("pbs", (A,)),
+                          ("qW1", (S + A, L1C)), ("qb1", (L1C,)), ("qW2", (L1C, L2C)), ("qb2", (L2C,)),
+                          ("qW3", (L2C, 1)), ("qb3", (1,)),
+                          ("vW1", (S, L1C)), ("vb1", (L1C,)), ("vW2", (L1C, L2C)), ("vb2", (L2C,)),
+                          ("vW3", (L2C, 1)), ("vb3", (1,))):
+            out[name] = (p, shp)
+            p += int(np.prod(shp))
+        return out, p
+
+    @property
+    def P(self):
+        return self.layout()[1]
+
+
+def init_params(dims, seed):
+    """nn.Linear's default init (kaiming_uniform(a=sqrt(5)): W, b ~ U(+-1/sqrt(fan_in))) for the hidden layers and
+    U(+-3e-3) for every output layer (reversekl_network.py:246-247,265-266,290-296); numpy RandomState(seed) instead of
+    torch's generator (distribution parity only)."""
+    rng = np.random.RandomState(seed)
+    lay, P = dims.layout()
+    th = np.zeros(P, np.float32)
+    fan = {}
+    for name, (off, shp) in lay.items():
+        n = int(np.prod(shp))
+        if name[1] == "W":
+            fan[name[0] + name[2:]] = shp[0]
+        if name[1:] in ("Wm", "bm", "Ws", "bs", "W3", "b3"):
+            lim = 3e-3
+        else:
+            lim = 1.0 / math.sqrt(fan[name[0] + name[2:]])
+        th[off:off + n] = rng.uniform(-lim, lim, n)
+    return th
+
+
+def _views(flat, lay):
+    return {k: flat[o:o + int(np.prod(s))].view(*s) for k, (o, s) in lay.items()}
+
+
+def _mlp3(p, pre, x):
+    h = torch.relu(x @ p[pre + "W1"] + p[pre + "b1"])
+    h = torch.relu(h @ p[pre + "W2"] + p[pre + "b2"])
+    return h @ p[pre + "W3"] + p[pre + "b3"]
+
+
+def _pi(p, s):
+    h = torch.relu(s @ p["pW1"] + p["pb1"])
+    h = torch.relu(h @ p["pW2"] + p["pb2"])
+    return h @ p["pWm"] + p["pbm"], torch.clamp(h @ p["pWs"] + p["pbs"], LOG_STD_MIN, LOG_STD_MAX)
+
+
+def _normal_logprob(value, mean, std):
+    # torch.distributions.Normal.log_prob
+    var = std ** 2
+    return -((value - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))
+
+
+def adam_171(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One step of torch 1.7.1's functional adam (no amsgrad, no weight decay), in place."""
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    m.mul_(beta1).add_(grad, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+class KLOracle(object):
+    def __init__(self, kind, dims, theta, pi_lr, qv_lr, alpha, tau, amax0, n_param, optim_type="intg",
+                 q_update_type="non_sac"):
+        assert kind in KINDS and optim_type in OPTIM_TYPES and q_update_type in Q_UPDATE_TYPES
+        if kind == "forward" and optim_type != "intg":
+            raise NotImplementedError("ForwardKL implements optim_type 'intg' only (forwardkl_network.py:153-158)")
+        assert dims.t[1] == 1, "the Clenshaw-Curtis line rule is the action_dim == 1 branch"
+        self.kind, self.d, self.optim_type, self.q_update_type = kind, dims, optim_type, q_update_type
+        self.lay, P = dims.layout()
+        self.theta = torch.tensor(np.asarray(theta, np.float32).copy())
+        self.theta_t = self.theta.clone()
+        self.m = torch.zeros(P)
+        self.v = torch.zeros(P)
+        self.step = 0
+        self.pi_lr, self.qv_lr, self.alpha, self.tau, self.amax0 = float(pi_lr), float(qv_lr), float(alpha), float(tau), float(amax0)
+        x, w = cc_rule(n_param)
+        # torch.tensor(points[1:-1], float32) * action_max (float64) -> float32   (reversekl_network.py:69-71)
+        self.nodes = torch.tensor((x[1:-1].astype(np.float32).astype(np.float64) * self.amax0).astype(np.float32))
+        self.weights = torch.tensor(w[1:-1].astype(np.float32))
+        self.pi_end = self.lay["qW1"][0]
+        self.q_end = self.lay["vW1"][0]
+
+    def act(self, states, eps=None):
+        """predict_action (eps None: tanh(mean) * action_max) / sample_action (tanh(mean + std*eps) * action_max)"""
+        S = self.d.t[0]
+        with torch.no_grad():
+            p = _views(self.theta, self.lay)
+            s = torch.tensor(np.asarray(states, np.float32).reshape(-1, S))
+            mean, log_std = _pi(p, s)
+            z = mean if eps is None else mean + log_std.exp() * torch.tensor(np.asarray(eps, np.float32).reshape(mean.shape))
+            return (torch.tanh(z) * self.amax0).numpy()
+
+    def update(self, s, a, s2, r, gam, eps, taps=False):
+        S, A = self.d.t[0], self.d.t[1]
+        B = len(np.reshape(r, -1))
+        f = lambda x, shp: torch.tensor(np.ascontiguousarray(x, np.float32).reshape(shp))
+        s, s2, a, eps = f(s, (B, S)), f(s2, (B, S)), f(a, (B, A)), f(eps, (B, A))
+        r, gam = f(r, (B, 1)), f(gam, (B, 1))
+        theta = self.theta.clone().requires_grad_(True)
+        p = _views(theta, self.lay)
+        pt = _views(self.theta_t, self.lay)
+        alpha, K = self.alpha, len(self.nodes)
+
+        q_val = _mlp3(p, "q", torch.cat([s, a], 1))
+        v_val = _mlp3(p, "v", s)
+        mean, log_std = _pi(p, s)
+        std = log_std.exp()
+        z = (mean + std * eps).detach()                       # normal.sample(): no gradient through the draw
+        action = torch.tanh(z)
+        log_prob = _normal_logprob(z, mean, std) - torch.log(1 - action.pow(2) + 1e-6).sum(-1, keepdim=True)
+        new_action = action * self.amax0
+
+        target_next_v = _mlp3(pt, "v", s2)
+        target_q = r + gam * target_next_v
+        q_loss = torch.nn.functional.mse_loss(q_val, target_q.detach())
+        new_q = _mlp3(p, "q", torch.cat([s, new_action], 1))
+        if self.q_update_type == "sac":
+            target_v = new_q - alpha * log_prob
+        else:
+            target_v = (r - alpha * log_prob) + gam * target_next_v
+        v_loss = torch.nn.functional.mse_loss(v_val, target_v.detach())
+
+        if self.optim_type in ("ll", "hard_ll"):
+            adv = new_q - v_val
+            if self.optim_type == "ll":
+                adv = adv - alpha * log_prob
+            pi_loss = (-log_prob * adv.detach()).mean()
+            intgrl_q = None
+        else:
+            stacked_s = s.unsqueeze(1).repeat(1, K, 1).reshape(-1, S)
+            tiled_a = self.nodes.view(1, K, 1).repeat(B, 1, 1)
+            intgrl_q = _mlp3(p, "q", torch.cat([stacked_s, tiled_a.reshape(-1, A)], 1)).reshape(B, K)
+            # get_logprob: nodes back through atanh, density of the pre-squash normal, squash correction
+            norm_a = tiled_a.permute(1, 0, 2) / self.amax0                             # [K, B, 1]
+            atanh_a = (torch.log(1 + norm_a) - torch.log(1 - norm_a)) / 2
+            lp = _normal_logprob(atanh_a, mean, std) - torch.log(1 - norm_a.pow(2) + 1e-6).sum(-1, keepdim=True)
+            lp = lp.permute(1, 0, 2).reshape(B, K)
+            if self.kind == "reverse":
+                adv = (intgrl_q - v_val).detach()
+                integrand = -torch.exp(lp) * (adv - alpha * lp if self.optim_type == "intg" else adv)
+                pi_loss = (integrand * self.weights).sum(-1).mean(-1)
+            else:
+                scaled = intgrl_q / alpha
+                shift, _ = torch.max(scaled, -1, keepdim=True)
+                expq = torch.exp(scaled - shift).detach()
+                zsum = (expq * self.weights).sum(-1, keepdim=True).detach()
+                pi_loss = (-((expq / zsum) * lp * self.weights).sum(-1)).mean(-1)
+
+        # three separate backward() calls in the reference; the three parameter sets are disjoint and each loss sees the
+        # other networks only through detached values, so one backward of the sum gives the same three gradients
+        (q_loss + v_loss + pi_loss).backward()
+        g = theta.grad
+        with torch.no_grad():
+            self.step += 1
+            for lo, hi, lr in ((self.pi_end, self.q_end, self.qv_lr), (self.q_end, len(g), self.qv_lr), (0, self.pi_end, self.pi_lr)):
+                adam_171(self.theta[lo:hi], g[lo:hi], self.m[lo:hi], self.v[lo:hi], self.step, lr)
+            # update_target_network: the V block only
+            vo = self.q_end
+            self.theta_t[vo:] = self.theta_t[vo:] * (1.0 - self.tau) + self.theta[vo:] * self.tau
+        if not taps:
+            return None
+        out = {"q": q_val, "v": v_val, "logp": log_prob, "q_pi": new_q, "grads": g, "z": z, "q_target": target_q,
+               "loss": torch.stack([pi_loss, q_loss, v_loss])}
+        if intgrl_q is not None:
+            out["intgrl_q"] = intgrl_q
+        return {k: t.detach().reshape(-1).numpy().copy() for k, t in out.items()}

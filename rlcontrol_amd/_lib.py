@@ -28,6 +28,9 @@ EXPORTS = (
     "rlc_sac_create", "rlc_sac_param_count", "rlc_sac_set_blob", "rlc_sac_get_blob", "rlc_sac_set_beta_powers",
     "rlc_sac_get_beta_powers", "rlc_sac_init_target", "rlc_sac_act", "rlc_sac_update", "rlc_sac_update_batch",
     "rlc_sac_last_tap", "rlc_sac_enable_grad_taps", "rlc_sac_set_kernel", "rlc_sac_get_kernel",
+    "rlc_kl_create", "rlc_kl_param_count", "rlc_kl_set_blob", "rlc_kl_get_blob", "rlc_kl_set_step", "rlc_kl_get_step",
+    "rlc_kl_init_target", "rlc_kl_act", "rlc_kl_update", "rlc_kl_update_batch", "rlc_kl_last_tap",
+    "rlc_kl_enable_grad_taps",
     "rlc_naf_create", "rlc_naf_param_count", "rlc_naf_set_blob", "rlc_naf_get_blob", "rlc_naf_get_beta_powers",
     "rlc_naf_init_target", "rlc_naf_act", "rlc_naf_update", "rlc_naf_update_batch", "rlc_naf_last_tap",
     "rlc_naf_enable_grad_taps", "rlc_naf_set_kernel", "rlc_naf_get_kernel",
@@ -67,6 +70,22 @@ class rlc_sac_config(ctypes.Structure):
         ("batch_size", ctypes.c_int32), ("clip_state", ctypes.c_int32), ("buffer_size", ctypes.c_int64),
         ("tau", ctypes.c_float), ("state_min0", ctypes.c_float), ("state_max0", ctypes.c_float),
         ("action_max0", ctypes.c_float),
+        ("pi_lr", ctypes.POINTER(ctypes.c_float)), ("qf_vf_lr", ctypes.POINTER(ctypes.c_float)),
+        ("entropy_scale", ctypes.POINTER(ctypes.c_float)), ("seed", ctypes.POINTER(ctypes.c_uint64)),
+    ]
+
+
+class rlc_kl_config(ctypes.Structure):
+    _fields_ = [
+        ("device", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("state_dim", ctypes.c_int32),
+        ("action_dim", ctypes.c_int32),
+        ("actor_l1_dim", ctypes.c_int32), ("actor_l2_dim", ctypes.c_int32), ("critic_l1_dim", ctypes.c_int32),
+        ("critic_l2_dim", ctypes.c_int32),
+        ("batch_size", ctypes.c_int32), ("kind", ctypes.c_int32), ("optim_type", ctypes.c_int32),
+        ("q_update_type", ctypes.c_int32), ("n_nodes", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("buffer_size", ctypes.c_int64),
+        ("tau", ctypes.c_float), ("action_max0", ctypes.c_float),
+        ("node_actions", ctypes.POINTER(ctypes.c_float)), ("node_weights", ctypes.POINTER(ctypes.c_float)),
         ("pi_lr", ctypes.POINTER(ctypes.c_float)), ("qf_vf_lr", ctypes.POINTER(ctypes.c_float)),
         ("entropy_scale", ctypes.POINTER(ctypes.c_float)), ("seed", ctypes.POINTER(ctypes.c_uint64)),
     ]

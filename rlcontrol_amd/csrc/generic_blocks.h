@@ -266,11 +266,24 @@ __device__ inline void blk_layernorm_bwd_rows(float* dY, const float* nhat, cons
 
 struct AdamCtx {
     float* theta; float* m; float* v; float alpha; float* tap;   // tap may be null
+    float eps = 1e-8f;   // TF's epsilon; torch's Adam (the KL agents) folds its bias correction into alpha and eps
 };
+
+// block-wide sum of v over threads (fixed order: deterministic); result broadcast to all threads
+__device__ inline float blk_sum(float v, float* red) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.0f;
+    for (int w = 0; w < kThreads / 64; w++) s += red[w];
+    __syncthreads();
+    return s;
+}
 
 __device__ __forceinline__ void adam_apply(const AdamCtx& c, int p, float g) {
     float m = c.m[p], v = c.v[p];
-    const float nv = adam_step(c.theta[p], g, m, v, c.alpha);
+    const float nv = adam_step_eps(c.theta[p], g, m, v, c.alpha, c.eps);
     c.m[p] = m; c.v[p] = v; c.theta[p] = nv;
     if (c.tap) c.tap[p] = g;
 }
@@ -314,7 +327,7 @@ __device__ inline void blk_grad_adam_tile4(const float* X, int ldx, int K, const
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 float mm = m[q], vv = v[q];
-                th[q] = adam_step(th[q], g[i][q], mm, vv, c.alpha);
+                th[q] = adam_step_eps(th[q], g[i][q], mm, vv, c.alpha, c.eps);
                 m[q] = mm; v[q] = vv;
             }
             *reinterpret_cast<gf4*>(&c.m[p]) = m;

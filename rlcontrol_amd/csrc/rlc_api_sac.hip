@@ -6,6 +6,11 @@
 #include "rlc_handle.h"
 
 #define RLC_NEED_SAC(h) RLC_REQUIRE((h) && (h)->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population")
+// the bodies below serve the SoftActorCritic handles and the ReverseKL / ForwardKL handles (rlc_api_kl.hip), which
+// share the device view RlcSacDev: `algo` is the one the calling entry point belongs to
+#define RLC_NEED_ALGO(h, algo)                                                                                  \
+    RLC_REQUIRE((h) && (h)->algo == (algo), "handle is not a %s population",                                    \
+                (algo) == RLC_ALGO_SAC ? "SoftActorCritic" : "ReverseKL / ForwardKL")
 
 namespace {
 
@@ -69,6 +74,10 @@ int upload_eps(rlc_handle* h, const float* eps, size_t count, const float** out_
 
 int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
                             const float* eps_dev, const RlcSacRollout* rollout) {
+    if (h->algo == RLC_ALGO_KL) {
+        RLC_REQUIRE(!rollout, "the on-device experiment loop does not implement the KL agents");
+        return rlc_launch_kl_update(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st);
+    }
     if (rlc_h_sac_variant(h) == 2) {
         RLC_REQUIRE(rlc_sac_mfma_supported(h->sac.d), "MFMA SAC kernel does not support these dimensions");
         return rlc_launch_sac_update_mfma(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st, rollout);
@@ -135,16 +144,16 @@ int rlc_sac_create(const rlc_sac_config* cfg, rlc_handle** out) {
     return 0;
 }
 
-int rlc_sac_param_count(const rlc_handle* h, int64_t* out_p) {
+int rlc_sacfam_param_count(int algo, const rlc_handle* h, int64_t* out_p) {
     RLC_REQUIRE(h && out_p, "null argument");
-    RLC_NEED_SAC(h);
+    RLC_NEED_ALGO(h, algo);
     *out_p = h->sac.d.P;
     return 0;
 }
 
-int rlc_sac_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* src, int64_t n) {
+int rlc_sacfam_set_blob(int algo, rlc_handle* h, int32_t agent, int32_t which, const float* src, int64_t n) {
     if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
-    RLC_NEED_SAC(h);
+    RLC_NEED_ALGO(h, algo);
     float* base = sac_blob(h, which);
     RLC_REQUIRE(base && src, "bad blob selector %d or null src", which);
     const RlcSacDims& d = h->sac.d;
@@ -156,9 +165,9 @@ int rlc_sac_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* s
     return 0;
 }
 
-int rlc_sac_get_blob(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+int rlc_sacfam_get_blob(int algo, rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
     if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
-    RLC_NEED_SAC(h);
+    RLC_NEED_ALGO(h, algo);
     float* base = sac_blob(h, which);
     RLC_REQUIRE(base && dst, "bad blob selector %d or null dst", which);
     RLC_REQUIRE(n == h->sac.d.P, "blob length %lld != parameter count %d", (long long)n, h->sac.d.P);
@@ -183,18 +192,18 @@ int rlc_sac_get_beta_powers(rlc_handle* h, int32_t agent, float* pw4) {
     return 0;
 }
 
-int rlc_sac_init_target(rlc_handle* h, int32_t agent) {
+int rlc_sacfam_init_target(int algo, rlc_handle* h, int32_t agent) {
     if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
-    RLC_NEED_SAC(h);
+    RLC_NEED_ALGO(h, algo);
     const size_t off = (size_t)agent * h->sac.d.Ppad;
     RLC_HIP(hipMemcpyAsync(h->sac.theta_t + off, h->sac.theta + off, h->sac.d.Ppad * sizeof(float),
                            hipMemcpyDeviceToDevice, h->st));
     return 0;
 }
 
-int rlc_sac_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
+int rlc_sacfam_act(int algo, rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
                 float* out_actions) {
-    RLC_NEED_SAC(h);
+    RLC_NEED_ALGO(h, algo);
     if (rlc_h_use_device(h)) return 1;
     RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->sac.n_agents, "agent range [%d,%d) invalid",
                 first_agent, first_agent + n);
@@ -207,8 +216,9 @@ int rlc_sac_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* sta
     for (size_t i = 0; i < eps_f; i++) hin[in_f + i] = eps[i];
     RLC_HIP(hipMemcpyAsync(h->io_dev, hin, sizeof(float) * (in_f + eps_f), hipMemcpyHostToDevice, h->st));
     float* dout = h->io_dev + in_f + eps_f;
-    if (rlc_launch_sac_act(h->sac, first_agent, n, h->io_dev, eps_f ? h->io_dev + in_f : nullptr, sample ? 1 : 0, dout,
-                           h->st))
+    if ((algo == RLC_ALGO_KL ? rlc_launch_kl_act : rlc_launch_sac_act)(h->sac, first_agent, n, h->io_dev,
+                                                                        eps_f ? h->io_dev + in_f : nullptr,
+                                                                        sample ? 1 : 0, dout, h->st))
         return 1;
     RLC_HIP(hipMemcpyAsync(hin + in_f + eps_f, dout, sizeof(float) * out_f, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
@@ -216,8 +226,8 @@ int rlc_sac_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* sta
     return 0;
 }
 
-int rlc_sac_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps) {
-    RLC_NEED_SAC(h);
+int rlc_sacfam_update(int algo, rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps) {
+    RLC_NEED_ALGO(h, algo);
     if (rlc_h_use_device(h)) return 1;
     RLC_REQUIRE(n_updates >= 0, "negative n_updates");
     if (n_updates == 0) return 0;
@@ -244,10 +254,10 @@ int rlc_sac_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices
     return rlc_h_sac_launch_update(h, 0, NA, n_updates, source, h->idx_dev, eps_dev, nullptr);
 }
 
-int rlc_sac_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+int rlc_sacfam_update_batch(int algo, rlc_handle* h, int32_t agent, int32_t batch, const double* states, const double* actions,
                          const double* next_states, const double* rewards, const double* gammas, const float* eps) {
     if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
-    RLC_NEED_SAC(h);
+    RLC_NEED_ALGO(h, algo);
     RLC_REQUIRE(batch == h->B, "minibatch has %d rows; the handle was created for batch_size %d", batch, h->B);
     RLC_REQUIRE(states && actions && next_states && rewards && gammas, "null minibatch array");
     const size_t S = h->sac.d.S, A = h->sac.d.A, B = batch;
@@ -288,8 +298,8 @@ int rlc_sac_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {
     return 0;
 }
 
-int rlc_sac_enable_grad_taps(rlc_handle* h, int32_t on) {
-    RLC_NEED_SAC(h);
+int rlc_sacfam_enable_grad_taps(int algo, rlc_handle* h, int32_t on) {
+    RLC_NEED_ALGO(h, algo);
     if (rlc_h_use_device(h)) return 1;
     if (on && !h->sac.tap_g) {
         if (rlc_h_malloc(h, &h->sac.tap_g, (size_t)h->sac.n_agents * h->sac.d.Ppad)) return 1;
@@ -298,9 +308,9 @@ int rlc_sac_enable_grad_taps(rlc_handle* h, int32_t on) {
     return 0;
 }
 
-int rlc_sac_last_tap(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+int rlc_sacfam_last_tap(int algo, rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
     if (rlc_h_check_agent(h, agent) || rlc_h_use_device(h)) return 2;
-    RLC_NEED_SAC(h);
+    RLC_NEED_ALGO(h, algo);
     RLC_REQUIRE(dst, "null dst");
     const int B = h->B, P = h->sac.d.P;
     const float* src = nullptr;
@@ -312,14 +322,45 @@ int rlc_sac_last_tap(rlc_handle* h, int32_t agent, int32_t which, float* dst, in
         case 3: src = h->sac.tap_qpi + (size_t)agent * RLC_MAX_BATCH; want = B; break;
         case 4: src = h->sac.tap_loss + (size_t)agent * 4; want = 3; break;
         case 5: src = h->sac.tap_g ? h->sac.tap_g + (size_t)agent * h->sac.d.Ppad : nullptr; want = P; break;
+        case 6:
+            if (algo == RLC_ALGO_KL && h->sac.kl_tap_iq) {
+                want = (long long)B * h->sac.kl_nodes;
+                src = h->sac.kl_tap_iq + (size_t)agent * want;
+            }
+            break;
         default: break;
     }
-    RLC_REQUIRE(src, "tap %d not available (gradient taps need rlc_sac_enable_grad_taps)", which);
+    RLC_REQUIRE(src, "tap %d not available (gradient taps need *_enable_grad_taps)", which);
     RLC_REQUIRE(n == want, "tap %d holds %lld floats, caller asked for %lld", which, want, (long long)n);
     if (which == 5) return sac_fetch_blob(h, src, dst);
     RLC_HIP(hipMemcpyAsync(dst, src, sizeof(float) * n, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     return 0;
+}
+
+// ---- the SoftActorCritic names of the shared bodies ----
+int rlc_sac_param_count(const rlc_handle* h, int64_t* out_p) { return rlc_sacfam_param_count(RLC_ALGO_SAC, h, out_p); }
+int rlc_sac_set_blob(rlc_handle* h, int32_t agent, int32_t which, const float* src, int64_t n) {
+    return rlc_sacfam_set_blob(RLC_ALGO_SAC, h, agent, which, src, n);
+}
+int rlc_sac_get_blob(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+    return rlc_sacfam_get_blob(RLC_ALGO_SAC, h, agent, which, dst, n);
+}
+int rlc_sac_init_target(rlc_handle* h, int32_t agent) { return rlc_sacfam_init_target(RLC_ALGO_SAC, h, agent); }
+int rlc_sac_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
+                float* out_actions) {
+    return rlc_sacfam_act(RLC_ALGO_SAC, h, first_agent, n, states, sample, eps, out_actions);
+}
+int rlc_sac_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps) {
+    return rlc_sacfam_update(RLC_ALGO_SAC, h, n_updates, host_indices, eps);
+}
+int rlc_sac_update_batch(rlc_handle* h, int32_t agent, int32_t batch, const double* states, const double* actions,
+                         const double* next_states, const double* rewards, const double* gammas, const float* eps) {
+    return rlc_sacfam_update_batch(RLC_ALGO_SAC, h, agent, batch, states, actions, next_states, rewards, gammas, eps);
+}
+int rlc_sac_enable_grad_taps(rlc_handle* h, int32_t on) { return rlc_sacfam_enable_grad_taps(RLC_ALGO_SAC, h, on); }
+int rlc_sac_last_tap(rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n) {
+    return rlc_sacfam_last_tap(RLC_ALGO_SAC, h, agent, which, dst, n);
 }
 
 }  // extern "C"

@@ -365,6 +365,14 @@ __device__ __forceinline__ float adam_step(float var, float g, float& m, float& 
     return var - (m * alpha) / (sqrtf(v) + 1e-8f);
 }
 
+// the same step with the epsilon as an argument (generic kernels: AdamCtx::eps)
+__device__ __forceinline__ float adam_step_eps(float var, float g, float& m, float& v, float alpha, float eps) {
+#pragma clang fp contract(off)
+    m += (g - m) * (1.0f - 0.9f);
+    v += (g * g - v) * (1.0f - 0.999f);
+    return var - (m * alpha) / (sqrtf(v) + eps);
+}
+
 // same update with the hardware sqrt / reciprocal (1 ulp each) instead of the IEEE-exact expansions:
 // ~10 VALU instead of ~30 per element; relative deviation ~2e-7, far inside the 1e-5 parity bar
 __device__ __forceinline__ float adam_step_fast(float var, float g, float& m, float& v, float alpha) {

@@ -6,7 +6,7 @@
 #include "sac_common.h"
 #include "naf_common.h"
 
-enum RlcAlgo { RLC_ALGO_DDPG = 1, RLC_ALGO_SAC = 2, RLC_ALGO_NAF = 3 };
+enum RlcAlgo { RLC_ALGO_DDPG = 1, RLC_ALGO_SAC = 2, RLC_ALGO_NAF = 3, RLC_ALGO_KL = 4 };   // KL: ReverseKL / ForwardKL, on RlcSacDev
 
 struct rlc_handle {
     int algo;
@@ -53,6 +53,22 @@ int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int 
                             const float* eps_dev, const struct RlcSacRollout* rollout);
 int rlc_h_naf_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
                             const struct RlcNafRollout* rollout);
+
+// bodies shared by the rlc_sac_* and rlc_kl_* entry points (rlc_api_sac.hip); algo = RLC_ALGO_SAC or RLC_ALGO_KL
+extern "C" {
+int rlc_sacfam_param_count(int algo, const rlc_handle* h, int64_t* out_p);
+int rlc_sacfam_set_blob(int algo, rlc_handle* h, int32_t agent, int32_t which, const float* src, int64_t n);
+int rlc_sacfam_get_blob(int algo, rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n);
+int rlc_sacfam_init_target(int algo, rlc_handle* h, int32_t agent);
+int rlc_sacfam_act(int algo, rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample,
+                   const float* eps, float* out_actions);
+int rlc_sacfam_update(int algo, rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps);
+int rlc_sacfam_update_batch(int algo, rlc_handle* h, int32_t agent, int32_t batch, const double* states,
+                            const double* actions, const double* next_states, const double* rewards,
+                            const double* gammas, const float* eps);
+int rlc_sacfam_enable_grad_taps(int algo, rlc_handle* h, int32_t on);
+int rlc_sacfam_last_tap(int algo, rlc_handle* h, int32_t agent, int32_t which, float* dst, int64_t n);
+}
 
 // shared helpers (rlc_api.hip)
 int rlc_h_check_agent(const rlc_handle* h, int agent);

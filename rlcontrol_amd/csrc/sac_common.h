@@ -13,6 +13,8 @@ struct RlcSacDims {
     int S, A, L1A, L2A, L1C, L2C, B;
     int blocked;     // 1: pW2 / qW2 / vW2 segments use the tile-blocked layout of rlc_common.h (MFMA kernel)
     int arow0;       // device row of qW2's first action row: L1C (row-major) or the next multiple of 16 (blocked)
+    int qcat;        // 0: the action joins Q at layer 2 (sac_network.py:183-196); 1: [state, action] is Q's INPUT
+                     // (the ReverseKL / ForwardKL SoftQNetwork, reversekl_network.py:257-276): qW1[S+A,L1c], qW2[L1c,L2c]
     int pW1, pb1, pW2, pb2, pWm, pbm, pWs, pbs, qW1, qb1, qW2, qb2, qW3, qb3, vW1, vb1, vW2, vb2, vW3, vb3;
     int Ppi_dev;     // device offset where the qf block starts (pi optimizer owns [0, Ppi_dev))
     int P, Pdev, Ppad, nseg;
@@ -21,13 +23,15 @@ struct RlcSacDims {
     char seg_big[RLC_SAC_NSEG];
 };
 
-inline RlcSacDims rlc_sac_make_dims(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, int blocked = 0) {
+inline RlcSacDims rlc_sac_make_dims(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, int blocked = 0,
+                                    int qcat = 0) {
     RlcSacDims d;
     d.S = S; d.A = A; d.L1A = L1A; d.L2A = L2A; d.L1C = L1C; d.L2C = L2C; d.B = B;
-    d.blocked = blocked;
+    d.blocked = blocked; d.qcat = qcat;
     d.arow0 = blocked ? ((L1C + 15) & ~15) : L1C;
     d.nseg = RLC_SAC_NSEG;
-    const int rows[RLC_SAC_NSEG] = {S, 1, L1A, 1, L2A, 1, L2A, 1, S, 1, L1C + A, 1, L2C, 1, S, 1, L1C, 1, L2C, 1};
+    const int rows[RLC_SAC_NSEG] = {S, 1, L1A, 1, L2A, 1, L2A, 1, qcat ? S + A : S, 1, qcat ? L1C : L1C + A, 1, L2C, 1,
+                                    S, 1, L1C, 1, L2C, 1};
     const int cols[RLC_SAC_NSEG] = {L1A, L1A, L2A, L2A, A, A, A, A, L1C, L1C, L2C, L2C, 1, 1, L1C, L1C, L2C, L2C, 1, 1};
     for (int i = 0; i < RLC_SAC_NSEG; i++) {
         d.seg_rows[i] = rows[i]; d.seg_cols[i] = cols[i];
@@ -56,6 +60,14 @@ struct RlcSacDev {
     float *tap_q, *tap_v, *tap_logp, *tap_qpi, *tap_loss, *tap_g;
     float* scratch;
     long long scratch_stride;
+    // ---- ReverseKL / ForwardKL populations (kl_generic.hip; zero for SoftActorCritic) ----
+    int kl_kind;                         // RLC_KL_REVERSE / RLC_KL_FORWARD
+    int kl_optim;                        // RLC_KL_OPTIM_*
+    int kl_qupdate;                      // RLC_KL_Q_NON_SAC / RLC_KL_Q_SAC
+    int kl_nodes;                        // quadrature nodes of the action integral
+    const float *kl_node_a, *kl_node_w;  // [kl_nodes] node actions (already scaled by action_max) and weights
+    int* kl_step;                        // [n_agents] Adam steps taken (torch keeps the step, not the beta powers)
+    float* kl_tap_iq;                    // [n_agents][B * kl_nodes] Q at the nodes of the last update
 };
 
 size_t rlc_sac_scratch_floats(const RlcSacDims& d);
@@ -70,6 +82,12 @@ bool rlc_sac_mfma_supported(const RlcSacDims& d);
 int rlc_launch_sac_update_mfma(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
                                const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
                                const RlcSacRollout* rollout = nullptr);
+// ReverseKL / ForwardKL fused update and acting (kl_generic.hip); same argument meaning as the SAC launches
+size_t rlc_kl_scratch_floats(const RlcSacDims& d, int nodes);
+int rlc_launch_kl_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                         const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st);
+int rlc_launch_kl_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
+                      int sample, float* out_dev, hipStream_t st);
 int rlc_launch_sac_eval(const RlcSacDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);
 // one state per agent; sample = 0 mean action, 1 reparameterised sample (eps_dev [n][A] or null -> Philox)
 int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,

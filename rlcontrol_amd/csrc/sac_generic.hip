@@ -54,18 +54,6 @@ __host__ __device__ inline size_t slds_carve(const RlcSacDims& d, unsigned char*
     return off;
 }
 
-// block-wide sum of v over threads (fixed order: deterministic); result broadcast to all threads
-__device__ inline float blk_sum(float v, float* red) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float s = 0.0f;
-    for (int w = 0; w < kThreads / 64; w++) s += red[w];
-    __syncthreads();
-    return s;
-}
-
 __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, int first_agent, int n_updates,
                                                                   int source, const long long* host_idx,
                                                                   const float* eps_in, int grad_taps,

@@ -37,8 +37,9 @@ __device__ inline float sac_act_eps(unsigned long long seed, unsigned long long 
 
 // L.x = clipped state (and L.eps[j] when sample != 0); on return L.out[j] = tanh(mu [+ eps*std]) * a_max.
 // Every thread of the workgroup (a multiple of 64 threads) calls it; trailing barrier included.
+// clamp_ls: 0 = SAC's log_std = -20 + 11*(tanh(.)+1); 1 = the KL agents' clamp(., -20, 2) (reversekl_network.py:318)
 __device__ inline void sac_policy_forward(const RlcSacDims& d, const float* th, const SacPolicyLds& L, float amax0,
-                                          int sample) {
+                                          int sample, int clamp_ls = 0) {
     const int S = d.S, A = d.A, L1A = d.L1A, L2A = d.L2A;
     const int tid = threadIdx.x, nthr = blockDim.x;
     __syncthreads();
@@ -69,7 +70,9 @@ __device__ inline void sac_policy_forward(const RlcSacDims& d, const float* th, 
         if (lane == 0) {
             float u = am + th[d.pbm + j];
             if (sample) {
-                const float log_std = -20.0f + 0.5f * (2.0f - (-20.0f)) * (tanhf(as + th[d.pbs + j]) + 1.0f);
+                const float raw = as + th[d.pbs + j];
+                const float log_std = clamp_ls ? fminf(fmaxf(raw, -20.0f), 2.0f)
+                                               : -20.0f + 0.5f * (2.0f - (-20.0f)) * (tanhf(raw) + 1.0f);
                 u += L.eps[j] * expf(log_std);
             }
             L.out[j] = tanhf(u) * amax0;

@@ -12,6 +12,8 @@ _AGENTS = {
     "DDPG": ("rlcontrol_amd.agents.DDPG", "DDPG"),
     "SoftActorCritic": ("rlcontrol_amd.agents.SoftActorCritic", "SoftActorCritic"),
     "NAF": ("rlcontrol_amd.agents.NAF", "NAF"),
+    "ReverseKL": ("rlcontrol_amd.agents.ReverseKL", "ReverseKL"),
+    "ForwardKL": ("rlcontrol_amd.agents.ForwardKL", "ForwardKL"),
 }
 
 
