@@ -263,6 +263,8 @@ def main():
     ap.add_argument("--updates-per-step", type=int, default=320,
                     help="updates of every agent per launch (320 x 20 steps = 6,400 timed updates per agent, > 2 s)")
     ap.add_argument("--kernel", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--split", type=int, default=1,
+                    help="latency mode: every agent's minibatch over this many CUs (rlc_ddpg_set_split; use with --agents 1..32)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="skip the SAC / NAF sub-records")
@@ -320,6 +322,9 @@ def main():
     red_dev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
     dt_max, gathered = reduce_over_ranks(dt, float(np.mean(pop.last_tap(0, "q"))), dist, world, red_dev)
     kernel = pop.kernel_in_use()
+    if args.split > 1:
+        pop.set_split(args.split)
+        kernel += "+split%d" % args.split
     pop.close()
 
     if rank == 0:

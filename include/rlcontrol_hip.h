@@ -139,6 +139,11 @@ int rlc_ddpg_update_batch(rlc_ddpg* h, int32_t agent, int32_t batch, const doubl
 /* kernel selection for A/B tests: 0 auto, 1 generic (any dims), 2 MFMA-tiled (gfx950 fp32 matrix cores) */
 int rlc_ddpg_set_kernel(rlc_ddpg* h, int32_t variant);
 int rlc_ddpg_get_kernel(const rlc_ddpg* h, int32_t* variant_in_use);
+/* latency mode (no reference counterpart): split every agent's minibatch over n_workgroups CUs (1 = off, at most 8;
+ * MFMA shapes only; n_agents rounded up to 8, times n_workgroups, must not exceed the CU count, and nothing else may
+ * occupy the GPU while an update runs: the workgroups of an agent meet at four barriers per update).  Results equal the
+ * one-workgroup kernel up to the summation order over the batch. */
+int rlc_ddpg_set_split(rlc_ddpg* h, int32_t n_workgroups);
 
 /* -- debug taps of the LAST update of one agent (the 1e-5 checks): which: 0 q before the critic step
  *    (train_critic's fetch, hydra_ddpg_network.py:155), 1 TD target y, 2 scaled actor output (DDPG.py:90),

@@ -40,6 +40,11 @@ class DDPG_Network_Manager(BaseNetwork_Manager):
         kernel = getattr(config, "hip_kernel", "auto")
         if kernel != "auto":
             self.population.set_kernel(kernel)
+        # optional json key "hip_split": latency mode, this one agent's minibatch over that many CUs (the GPU must not
+        # be shared with other processes while it learns: the workgroups meet at barriers)
+        split = int(getattr(config, "hip_split", 1))
+        if split > 1:
+            self.population.set_split(split)
         # sess.run(global_variables_initializer()) + init_target_network() (agents/DDPG.py:28-32)
         theta0 = init_params(config.state_dim, config.action_dim, config.shared_l1_dim, config.actor_l2_dim,
                              config.critic_l2_dim, config.random_seed, config.norm_type, separate)

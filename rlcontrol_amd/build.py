@@ -14,13 +14,14 @@ CSRC = os.path.join(_HERE, "csrc")
 STAMPS = os.environ.get("RLC_STAMPS", "0") == "1"
 OBJ = os.path.join(CSRC, ("_obj_stamps" if STAMPS else "_obj") + ("_fast" if os.environ.get("RLC_FAST_BUILD", "0") == "1" else ""))
 OUT = os.path.join(_HERE, "librlcontrol_hip_stamps.so" if STAMPS else "librlcontrol_hip.so")
-PLAIN = ("rlc_api.hip", "rlc_api_sac.hip", "rlc_api_naf.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip", "sac_generic.hip", "sac_mfma.hip", "naf_generic.hip", "naf_mfma.hip", "rollout_kernels.hip", "rlc_api_rollout.hip", "kl_generic.hip", "rlc_api_kl.hip")
+PLAIN = ("rlc_api.hip", "rlc_api_sac.hip", "rlc_api_naf.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip", "sac_generic.hip", "sac_mfma.hip", "naf_generic.hip", "naf_mfma.hip", "rollout_kernels.hip", "rlc_api_rollout.hip", "kl_generic.hip", "rlc_api_kl.hip", "ddpg_split.hip")
 MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]
 FAST = os.environ.get("RLC_FAST_BUILD", "0") == "1"     # developer loop: only the headline shape
 SAC_VARIANTS = [(mt, ntw, ad) for ad in (1, 2) for ntw in (1, 2) for mt in (2, 4, 7, 8)]
 if FAST:
     MFMA_VARIANTS = [(7, 1)]
     SAC_VARIANTS = [(7, 1, 1)]
+SPLIT_VARIANTS = [(2, 1)] if FAST else [(mt, ad) for ad in (1, 2) for mt in (1, 2, 4)]
 NAF_VARIANTS = [(7, 2, 2)] if FAST else [(mt, ntw, ad) for ad in (1, 2) for ntw in (1, 2) for mt in (2, 4, 7, 8)]
 # -fgpu-flush-denormals-to-zero: TF-1.15's CPU kernels flush denormals (the reference's checkpoints show it: beta1
 # power exactly 0, idle Adam m slots resting at 9..10 x FLT_MIN; tests/test_ckpt_pins.py) -- the kernels' fp32 VALU
@@ -46,6 +47,9 @@ def _units():
     units = [(os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o")), []) for s in PLAIN]
     for mt, ad in MFMA_VARIANTS:
         units.append((os.path.join(CSRC, "ddpg_mfma_inst.hip"), os.path.join(OBJ, "ddpg_mfma_%d_%d.o" % (mt, ad)),
+                      ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
+    for mt, ad in SPLIT_VARIANTS:
+        units.append((os.path.join(CSRC, "ddpg_split_inst.hip"), os.path.join(OBJ, "ddpg_split_%d_%d.o" % (mt, ad)),
                       ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
     for mt, ntw, ad in SAC_VARIANTS:
         units.append((os.path.join(CSRC, "sac_mfma_inst.hip"), os.path.join(OBJ, "sac_mfma_%d_%d_%d.o" % (mt, ntw, ad)),

@@ -779,14 +779,16 @@ struct Blk {
     // epilogue of bwd_gemm: dh1 = (acc [+ extra(b, k)]) * (hbuf > 0); column-reduce into the W1 / b1 gradients of
     // this wave's first-layer units and apply Adam (+ optional Polyak) right here.  xs = the layer's input rows
     // (LDS [MB][SMAX]).  extra(b, k): further contributions to dL/dh1[b][k] (heads that hang off the first layer).
-    template <class EXTRA = NoExtra>
+    // GONLY: only the gradient is produced (written to `tap`, which must not be null); no Adam, no Polyak -- the
+    // batch-split kernel (ddpg_split_kernel.h) reduces such partial gradients over the CUs of an agent first.
+    template <class EXTRA = NoExtra, bool GONLY = false>
     __device__ __forceinline__ void trunk_grad_adam(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
                                                     float alpha, int oW1, int ob1, float* tap, float* tt, float tau,
                                                     const lds_f32* xs, EXTRA extra = EXTRA{}) {
-        if (S <= 4) trunk_grad_adam_t<4>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);     // wave-uniform
-        else trunk_grad_adam_t<SMAX>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);
+        if (S <= 4) trunk_grad_adam_t<4, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);     // wave-uniform
+        else trunk_grad_adam_t<SMAX, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);
     }
-    template <int SP, class EXTRA>
+    template <int SP, class EXTRA, bool GONLY = false>
     __device__ __forceinline__ void trunk_grad_adam_t(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
                                                       float alpha, int oW1, int ob1, float* tap, float* tt, float tau,
                                                       const lds_f32* xs, EXTRA extra) {
@@ -834,11 +836,15 @@ struct Blk {
                     for (int q = 0; q < SP; q++)
                         if (q == s && !is_bias) gr = gw[q];
                     const int p = is_bias ? ob1 + k : oW1 + s * H1 + k;
-                    float mm = m[p], vv = v[p];
-                    const float nv = RLC_ADAM_SMALL(th[p], gr, mm, vv, alpha);
-                    m[p] = mm; v[p] = vv; th[p] = nv;
-                    if (tap) tap[p] = gr;
-                    if (tt) tt[p] = polyak(tt[p], nv, tau);
+                    if constexpr (GONLY) {
+                        tap[p] = gr;
+                    } else {
+                        float mm = m[p], vv = v[p];
+                        const float nv = RLC_ADAM_SMALL(th[p], gr, mm, vv, alpha);
+                        m[p] = mm; v[p] = vv; th[p] = nv;
+                        if (tap) tap[p] = gr;
+                        if (tt) tt[p] = polyak(tt[p], nv, tau);
+                    }
                 }
             }
         }
@@ -859,7 +865,8 @@ struct Blk {
     // ---------------------------------------------------------------------------------------
     struct WgPre { f32x4 w[4], m[4], v[4], t[4]; };
 
-    template <int NS, int NE, int BIT = -1>
+    // GONLY: as in trunk_grad_adam -- the gradient tiles go to `tapp` (not null), nothing else is read or written.
+    template <int NS, int NE, int BIT = -1, bool GONLY = false>
     __device__ __forceinline__ void wgrad_adam(const lds_f32* seed /* LDS [MB][NS] */, const lds_f32* E /* LDS [MB][NE] or null */,
                                                int N, float* Wp, float* mp, float* vp,
                                                float alpha, float* tapp, float* Wt, float tau,
@@ -881,6 +888,7 @@ struct Blk {
         // Prefetch an item's W / m / v / W' NOW: their HBM latency hides under the previous item's k-loop
         // (addresses clamped, stores predicated).
         auto issue = [&](WgPre& P, int idx) {
+            if constexpr (GONLY) return;
             int t, m0, nq;
             item_geom(idx, t, m0, nq);
             const bool n4ok = 16 * t + 4 * g < N;        // N % 4 == 0: all four columns valid or none
@@ -966,6 +974,11 @@ struct Blk {
 #pragma unroll
             for (int q = 0; q < MCC; q++) {
                 const int kp = 16 * (m0 + q) + c;
+                if constexpr (GONLY) {
+                    if (q < nq && kp < H1 && n4ok)
+                        *reinterpret_cast<f32x4*>(&tapp[(((size_t)(m0 + q) * NT + t) << 8) + lane4]) = acc[q];
+                    continue;
+                }
                 f32x4 nw, nm = P.m[q], nv = P.v[q], nt;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1043,6 +1056,7 @@ struct Blk {
                     const float gr = col4_sum(ge[j]);
                     if (g == j && nok) {
                         const size_t p = rlc_blk_index(((H1 + 15) & ~15) + j, n, N);   // first extra block row + j
+                        if constexpr (GONLY) { tapp[p] = gr; continue; }
                         float mm = mp[p], vv = vp[p];
                         const float nv = RLC_ADAM_SMALL(Wp[p], gr, mm, vv, alpha);
                         mp[p] = mm; vp[p] = vv; Wp[p] = nv;

@@ -135,6 +135,7 @@ int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, 
     h->io_host = nullptr; h->io_host_cap = 0;
     h->io_pending = false;
     h->variant = 0;
+    h->split_c = 1; h->split_part = nullptr; h->split_bar = nullptr; h->split_err = nullptr;
     h->grad_taps = 0;
     h->has_env = false;
     memset(&h->env, 0, sizeof(h->env));
@@ -572,6 +573,17 @@ static int relayout(rlc_handle* h, int blocked) {
 
 static int launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev) {
     const int v = pick_variant(h);
+    if (v == 2 && h->split_c > 1) {
+        if (rlc_launch_ddpg_update_split(h->dv, h->split_part, h->split_bar, h->split_err, h->split_c, first, n, n_updates,
+                                         source, idx_dev, h->grad_taps, h->st))
+            return 1;
+        // a barrier that timed out (a peer workgroup was not resident) must not pass for a finished update
+        int err = 0;
+        RLC_HIP(hipMemcpyAsync(&err, h->split_err, sizeof(int), hipMemcpyDeviceToHost, h->st));
+        RLC_HIP(hipStreamSynchronize(h->st));
+        RLC_REQUIRE(err == 0, "split update: a cross-workgroup barrier timed out (the GPU is shared with other work?)");
+        return 0;
+    }
     if (v == 2) {
         RLC_REQUIRE(rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
         return rlc_launch_ddpg_update_mfma(h->dv, first, n, n_updates, source, idx_dev, h->grad_taps, h->st);
@@ -638,6 +650,30 @@ int rlc_ddpg_set_kernel(rlc_handle* h, int32_t variant) {
     RLC_REQUIRE(!h->has_env, "the kernel variant cannot change once a rollout is attached to the handle");
     h->variant = variant;
     return relayout(h, pick_variant(h) == 2 ? 1 : 0);
+}
+
+int rlc_ddpg_set_split(rlc_handle* h, int32_t n_workgroups) {
+    RLC_REQUIRE(h, "null handle");
+    RLC_NEED_DDPG(h);
+    if (use_device(h)) return 1;
+    RLC_REQUIRE(n_workgroups >= 1 && n_workgroups <= 8, "workgroups per agent must be in [1,8]");
+    RLC_REQUIRE(!h->has_env, "the on-device experiment loop runs the one-workgroup kernels");
+    if (n_workgroups == 1) { h->split_c = 1; return 0; }
+    RLC_REQUIRE(pick_variant(h) == 2, "the split update is a variant of the MFMA kernel (these dimensions run the generic one)");
+    RLC_REQUIRE(rlc_split_mt(h->dv.d.B, n_workgroups) > 0, "batch_size %d does not fit %d workgroups of at most 64 rows",
+                h->dv.d.B, n_workgroups);
+    hipDeviceProp_t prop;
+    RLC_HIP(hipGetDeviceProperties(&prop, h->device));
+    const int grid = (h->dv.n_agents + 7) / 8 * 8 * n_workgroups;
+    RLC_REQUIRE(grid <= prop.multiProcessorCount, "%d agents x %d workgroups need %d co-resident workgroups; the GPU has %d CUs",
+                h->dv.n_agents, n_workgroups, grid, prop.multiProcessorCount);
+    if (!h->split_bar) {
+        if (rlc_h_malloc(h, &h->split_bar, (size_t)h->dv.n_agents) || rlc_h_malloc(h, &h->split_err, (size_t)1)) return 1;
+    }
+    // partial-gradient blobs: zeroed once, the kernels only ever write real parameter slots
+    if (rlc_h_malloc(h, &h->split_part, (size_t)h->dv.n_agents * n_workgroups * h->dv.d.Ppad)) return 1;
+    h->split_c = n_workgroups;
+    return 0;
 }
 
 int rlc_ddpg_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {

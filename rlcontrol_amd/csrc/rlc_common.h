@@ -269,6 +269,12 @@ int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agen
                                    const RlcRollout* rollout = nullptr, int q8_first = 0);
 // MFMA-tiled fused update (dims must satisfy rlc_mfma_supported)
 bool rlc_mfma_supported(const RlcDims& d);
+// batch-split latency mode (ddpg_split.hip): C workgroups per agent; part [n_agents][C][Ppad] zero-initialised, bar
+// [n_agents], err [1]; rlc_split_mt: M tiles per workgroup for (batch, C), 0 if unsupported
+int rlc_split_mt(int B, int C);
+int rlc_launch_ddpg_update_split(const RlcDev& dv, float* part, unsigned int* bar, int* err, int C, int first_agent,
+                                 int n_agents, int n_updates, int source, const long long* idx_dev, int grad_taps,
+                                 hipStream_t st);
 int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source,
                                 const long long* idx_dev, int grad_taps, hipStream_t st,
                                 const RlcRollout* rollout = nullptr, int q8_first = 0);

@@ -25,6 +25,8 @@ struct rlc_handle {
     RlcDev dv;
     int variant;                         // requested kernel: 0 auto, 1 generic, 2 mfma
     int grad_taps;
+    int split_c;                         // > 1: latency mode, one agent's minibatch over split_c workgroups (ddpg_split.hip)
+    float* split_part; unsigned int* split_bar; int* split_err;
     // ---- SAC
     RlcSacDev sac;
     // ---- NAF

@@ -160,6 +160,10 @@ class DDPGPopulation(Population):
     def set_kernel(self, name):
         check(self._lib.rlc_ddpg_set_kernel(self._h, self.KERNEL[name]))
 
+    def set_split(self, n_workgroups):
+        """latency mode: every agent's minibatch over n_workgroups CUs (1 = off); MFMA shapes only"""
+        check(self._lib.rlc_ddpg_set_split(self._h, ctypes.c_int32(int(n_workgroups))))
+
     def kernel_in_use(self):
         out = ctypes.c_int32(0)
         check(self._lib.rlc_ddpg_get_kernel(self._h, ctypes.byref(out)))

@@ -355,3 +355,93 @@ def test_device_sampler_updates_equal_oracle_on_the_same_philox_minibatches(hip_
         assert _rel(dev[name], orc[name]) < 2e-4, name
     assert np.allclose(pop.get_beta_powers(0), o.pw, rtol=1e-6)
     pop.close()
+
+
+# ------------------------------------------------------------------ latency mode: one agent over several CUs
+SPLIT_CASES = [((3, 1, 200, 200, 200), 100, 4), ((3, 1, 200, 200, 200), 100, 7), ((3, 1, 200, 200, 200), 100, 2),
+               ((3, 1, 200, 200, 200), 32, 2), ((8, 2, 200, 160, 144), 64, 4), ((3, 1, 128, 128, 128), 128, 8),
+               ((3, 1, 200, 200, 200), 32, 4)]       # the last one leaves two workgroups without rows
+
+
+@pytest.mark.parametrize("dims,B,C", SPLIT_CASES)
+def test_split_update_single_step_matches_oracle(hip_lib, dims, B, C):
+    """rlc_ddpg_set_split: the minibatch of one agent over C workgroups, partial gradients reduced over them.
+    Same taps and gradients as the oracle at 1e-5 (only the summation order over the batch differs)."""
+    from oracle.ddpg import Dims, init_params
+    pop, smin, smax, amax = _make(dims, B, kernel="mfma")
+    pop.set_split(C)
+    pop.enable_grad_taps(True)
+    th = init_params(Dims(*dims), 3)
+    pop.set_params(0, th)
+    o = _oracle(dims, th, (1e-3, 1e-2), smin, smax, amax)
+    rng = np.random.RandomState(11)
+    s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+    pop.update_batch(0, s, a, s2, r, g)
+    taps = o.update(s, a, s2, r, g, taps=True)
+    for name in ("q", "y", "a_out", "dqda"):
+        assert _rel(pop.last_tap(0, name), taps[name]) < 1e-5, name
+    lay, P = Dims(*dims).layout()
+    for which in ("grads_c", "grads_a"):
+        got, want = pop.last_tap(0, which), taps[which]
+        assert _cos(got, want) > 1 - 1e-9, which
+        for name, (off, shp) in lay.items():
+            n = int(np.prod(shp))
+            if np.any(want[off:off + n]):
+                assert _rel(got[off:off + n], want[off:off + n]) < 1e-5, (which, name)
+            else:
+                assert not np.any(got[off:off + n]), (which, name)
+    assert _rel(pop.get_blob(0, "theta_target"), o.theta_t) < 1e-5
+    assert np.allclose(pop.get_beta_powers(0), o.pw, rtol=1e-6)
+    pop.close()
+
+
+@pytest.mark.parametrize("C", [2, 4, 7])
+def test_split_trajectory_follows_the_one_workgroup_kernel(hip_lib, C):
+    """Six updates from the replay (host indices, then the device sampler, several updates per launch, two agents with
+    their own learning rates): the split population stays on the one-workgroup MFMA kernel's trajectory."""
+    from oracle.ddpg import Dims, init_params
+    dims, B, N = (3, 1, 200, 200, 200), 100, 3000
+    rng = np.random.RandomState(3)
+    data = (rng.randn(N, 3), rng.randn(N, 1), rng.randn(N), rng.randn(N, 3), np.full(N, 0.99))
+    idx = np.stack([rng.choice(N, B, replace=False) for _ in range(6)]).reshape(2, 3, B).astype(np.int64)
+    pops = []
+    for split in (1, C):
+        pop, _, _, _ = _make(dims, B, n_agents=2, cap=N, kernel="mfma", lr=([1e-3, 3e-4], [1e-2, 3e-3]))
+        pop.set_split(split)
+        for i in range(2):
+            pop.set_params(i, init_params(Dims(*dims), 5 + i))
+            pop.replay_add_batch(i, *data)
+        pop.update(3, host_indices=idx)
+        pop.update(2)                    # device sampler: every workgroup draws the same index set
+        pop.update(1)
+        pops.append(pop)
+    a, b = pops
+    for i in range(2):
+        for name in ("q", "y", "a_out", "dqda"):
+            assert _rel(b.last_tap(i, name), a.last_tap(i, name)) < 2e-4, (i, name)
+        for w in ("theta", "theta_target"):
+            assert _rel(b.get_blob(i, w), a.get_blob(i, w)) < 2e-4, (i, w)
+        assert np.array_equal(b.get_beta_powers(i), a.get_beta_powers(i))
+    # the sampler's stream position advanced identically: one more update draws the same minibatch on both
+    for p in pops:
+        p.update(1)
+    assert _rel(b.last_tap(0, "y"), a.last_tap(0, "y")) < 2e-4
+    for p in pops:
+        p.close()
+
+
+def test_split_is_refused_where_it_cannot_run(hip_lib):
+    from rlcontrol_amd._lib import RlcError
+    pop, _, _, _ = _make((3, 1, 200, 200, 200), 100, n_agents=64, kernel="mfma")
+    with pytest.raises(RlcError, match="co-resident"):
+        pop.set_split(8)                 # 64 agents x 8 workgroups > 256 CUs
+    pop.set_split(4)                     # 64 x 4 = 256: accepted
+    pop.set_split(1)
+    pop.close()
+    pop, _, _, _ = _make((3, 1, 128, 128, 128), 128, kernel="mfma")
+    pop.set_split(2)                     # 2 x 64 rows
+    pop.close()
+    pop, _, _, _ = _make((8, 2, 64, 48, 40), 17, kernel="generic")
+    with pytest.raises(RlcError, match="MFMA"):
+        pop.set_split(2)
+    pop.close()
