@@ -48,6 +48,16 @@ PEAK_HBM = 8.0e12                 # MI355X_MICROARCH.md: HBM3E spec peak
 SAC_SHAPE = dict(S=3, A=1, L=128)
 SAC_FLOP_PER_UPDATE = 168832 * 2 * 100.0
 SAC_BYTES_PER_UPDATE = 51716 * 4 * 4 * 2 + 100 * (2 * 3 + 1 + 2) * 4.0
+# ReverseKL (jsonfiles/agent/reverse_kl.json): batch 32 (the reference's default), N_param 64 -> K = 62 nodes.
+# multiply-adds x 2: pi, V, V' forward + Q(s,a), Q(s,a_new) forward + Q at the B*K (state, node) pairs + the input and
+# weight gradients of the three trained networks
+KL_SHAPE = dict(S=3, A=1, L=200, B=32, N_PARAM=64)
+def _kl_flop(B=32, K=62, S=3, L=200):
+    fwd = lambda rows, k_in: 2 * rows * (k_in * L + L * L + L)
+    return float(fwd(B, S) * 3 + fwd(B, S + 1) * 2 + fwd(B * K, S + 1) + 3 * 2 * B * (L * L + L)
+                 + 3 * 2 * B * (L * L + (S + 1) * L + 2 * L))
+KL_FLOP_PER_UPDATE = _kl_flop()
+KL_BYTES_PER_UPDATE = 124004 * 4 * 4 * 2 + 32 * (2 * 3 + 1 + 2) * 4.0
 NAF_SHAPE = dict(S=8, A=2, L=200)
 NAF_FLOP_PER_UPDATE = 288600 * 2 * 100.0
 NAF_BYTES_PER_UPDATE = 83406 * 4 * 4 * 2 + 100 * (2 * 8 + 2 + 2) * 4.0
@@ -222,7 +232,8 @@ def _fill_from_host(pop, host, torch):
 
 
 def side_record(algo, NA, U, steps, warmup, torch, device):
-    """BASELINE configs[2] / [3]: the SAC-v1 / NAF fused update kernels on 256 agents x 1e6-record replays."""
+    """BASELINE configs[2] / [3] (SAC-v1 / NAF) and the ReverseKL agent of SURVEY section 8(f) item 4: their fused update
+    kernels on 256 agents x 1e6-record replays."""
     seeds = np.arange(NA, dtype=np.uint64) + 1
     if algo == "sac":
         from rlcontrol_amd.hip_sac import SACPopulation, init_params
@@ -234,6 +245,17 @@ def side_record(algo, NA, U, steps, warmup, torch, device):
         host = synthetic_uniform_replay(REPLAY_N, SAC_SHAPE["S"], SAC_SHAPE["A"])
         flop, byts = SAC_FLOP_PER_UPDATE, SAC_BYTES_PER_UPDATE
         wl = "SoftActorCritic (SAC-v1) on synthetic replay (1e6 transitions/agent), obs=3 act=1 l1=l2=128 batch=100"
+    elif algo == "kl":
+        from rlcontrol_amd.hip_kl import KLPopulation, init_params
+        L = KL_SHAPE["L"]
+        pop = KLPopulation("reverse", NA, KL_SHAPE["S"], KL_SHAPE["A"], L, L, L, L, KL_SHAPE["B"], REPLAY_N, 0.01, 2.0, 1e-3,
+                           1e-3, 0.1, seeds=seeds, n_param=KL_SHAPE["N_PARAM"], device=device)
+        for i in range(NA):
+            pop.set_params(i, init_params(KL_SHAPE["S"], KL_SHAPE["A"], L, L, L, L, int(seeds[i])))
+        host = synthetic_uniform_replay(REPLAY_N, KL_SHAPE["S"], KL_SHAPE["A"])
+        flop, byts = KL_FLOP_PER_UPDATE, KL_BYTES_PER_UPDATE
+        wl = ("ReverseKL (optim_type intg, N_param 64) on synthetic replay (1e6 transitions/agent), obs=3 act=1 "
+              "four 200-wide layers batch=32: 1984 Q evaluations per update")
     else:
         from rlcontrol_amd.hip_naf import NAFPopulation, init_params
         L = NAF_SHAPE["L"]
@@ -356,8 +378,9 @@ def main():
         if world == 1 and not args.no_side_records:
             # BASELINE configs[2], [3] on the same box, same agent count and replay size (extra keys; `value` is DDPG)
             side_U = max(1, U // 4)
-            for algo in ("sac", "naf"):
-                out[algo] = side_record(algo, NA, side_U, args.steps, args.warmup, torch, local_rank)
+            for algo in ("sac", "naf", "kl"):
+                out[algo] = side_record(algo, NA, side_U if algo != "kl" else max(1, U // 8), args.steps, args.warmup,
+                                        torch, local_rank)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

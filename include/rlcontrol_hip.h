@@ -266,6 +266,10 @@ int rlc_kl_update_batch(rlc_kl* h, int32_t agent, int32_t batch, const double* s
  * the integral updates only) */
 int rlc_kl_last_tap(rlc_kl* h, int32_t agent, int32_t which, float* dst, int64_t n);
 int rlc_kl_enable_grad_taps(rlc_kl* h, int32_t on);
+/* kernel selection, as rlc_sac_set_kernel: 0 auto, 1 generic, 2 MFMA (state_dim <= 7, widths multiples of 4 in
+ * [16,256], batch_size <= 32, at most 256 nodes, LDS permitting) */
+int rlc_kl_set_kernel(rlc_kl* h, int32_t variant);
+int rlc_kl_get_kernel(const rlc_kl* h, int32_t* variant_in_use);
 
 
 /* ===================================== NAF =========================================================

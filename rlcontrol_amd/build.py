@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 STAMPS = os.environ.get("RLC_STAMPS", "0") == "1"
 OBJ = os.path.join(CSRC, ("_obj_stamps" if STAMPS else "_obj") + ("_fast" if os.environ.get("RLC_FAST_BUILD", "0") == "1" else ""))
 OUT = os.path.join(_HERE, "librlcontrol_hip_stamps.so" if STAMPS else "librlcontrol_hip.so")
-PLAIN = ("rlc_api.hip", "rlc_api_sac.hip", "rlc_api_naf.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip", "sac_generic.hip", "sac_mfma.hip", "naf_generic.hip", "naf_mfma.hip", "rollout_kernels.hip", "rlc_api_rollout.hip", "kl_generic.hip", "rlc_api_kl.hip", "ddpg_split.hip")
+PLAIN = ("rlc_api.hip", "rlc_api_sac.hip", "rlc_api_naf.hip", "replay_kernels.hip", "ddpg_generic.hip", "ddpg_mfma.hip", "sac_generic.hip", "sac_mfma.hip", "naf_generic.hip", "naf_mfma.hip", "rollout_kernels.hip", "rlc_api_rollout.hip", "kl_generic.hip", "rlc_api_kl.hip", "ddpg_split.hip", "kl_mfma.hip")
 MFMA_VARIANTS = [(mt, ad) for ad in (1, 2) for mt in (2, 4, 7, 8)]
 FAST = os.environ.get("RLC_FAST_BUILD", "0") == "1"     # developer loop: only the headline shape
 SAC_VARIANTS = [(mt, ntw, ad) for ad in (1, 2) for ntw in (1, 2) for mt in (2, 4, 7, 8)]

@@ -1,0 +1,21 @@
+// kl_mfma.hip -- shape check + launch of the MFMA ReverseKL / ForwardKL update kernel (kl_mfma_kernel.h).
+// One instantiation: 2 batch tiles for the three small networks (batch_size <= 32, the reference's default),
+// 7 batch tiles per pass of the action integral.
+#include "kl_mfma_kernel.h"
+
+bool rlc_kl_mfma_supported(const RlcSacDims& d, int nodes) {
+    auto okdim = [](int h) { return h >= 16 && h <= 256 && (h % 4) == 0; };
+    if (!d.qcat || d.A != 1) return false;
+    if (!(okdim(d.L1A) && okdim(d.L2A) && okdim(d.L1C) && okdim(d.L2C))) return false;
+    if (d.S < 1 || d.S + 1 > SMAX) return false;
+    if (d.B < 1 || d.B > 32) return false;
+    if (nodes < 0 || nodes > KL_MAXNODES) return false;
+    return ksmem_carve(d, 2, 7, nullptr, nullptr) <= 160 * 1024;
+}
+
+int rlc_launch_kl_update_mfma(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
+                              const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st) {
+    RLC_REQUIRE(rlc_kl_mfma_supported(dv.d, dv.kl_nodes), "MFMA KL kernel does not support these dimensions");
+    RLC_REQUIRE(dv.d.blocked, "the MFMA kernel reads tile-blocked weights (rlc_kl_set_kernel re-packs them)");
+    return kl_launch_t<2, 7>(dv, first_agent, n_agents, n_updates, source, idx_dev, eps_dev, grad_taps, st);
+}

@@ -102,7 +102,9 @@ struct NoExtra {};
 // MT: M tiles (batch rows / 16); NTW: N tiles per wave (1: widths <= 128, 2: widths <= 256); MSTRIDE: mask row bytes;
 // LERP: target update written (1-tau)*t + tau*w (sac_network.py:72-73) instead of t + tau*(w - t)
 // (hydra_ddpg_network.py:29, naf_network.py:62-63)
-template <int MT, int NTW, int MSTRIDE, bool LERP = false>
+// TADAM: torch.optim.Adam's step (the KL agents): the caller folds sqrt(1 - b2^t) into alpha and sets adam_eps =
+// 1e-8 * sqrt(1 - b2^t) (see kl_generic.hip); otherwise TF's ApplyAdam with its constant epsilon
+template <int MT, int NTW, int MSTRIDE, bool LERP = false, bool TADAM = false>
 struct Blk {
     static constexpr int MB = MT * 16;
 
@@ -114,6 +116,15 @@ struct Blk {
     int tid, lane, wave, c, g;
     int S, H1, B, LDH;      // H1 = width of the activation held in hbuf (k-dim of the forward GEMMs)
     BlkLds L;
+    float adam_eps;         // TADAM only
+    __device__ __forceinline__ float astep_big(float w, float gr, float& m, float& v, float alpha) const {
+        if constexpr (TADAM) return adam_step_fast_eps(w, gr, m, v, alpha, adam_eps);
+        else return adam_step_fast(w, gr, m, v, alpha);
+    }
+    __device__ __forceinline__ float astep_small(float w, float gr, float& m, float& v, float alpha) const {
+        if constexpr (TADAM) return adam_step_fast_eps(w, gr, m, v, alpha, adam_eps);
+        else return RLC_ADAM_SMALL(w, gr, m, v, alpha);
+    }
 #ifdef RLC_STAMPS
     float* stamp_buf = nullptr;
     long long t_sub = 0;
@@ -840,7 +851,7 @@ struct Blk {
                         tap[p] = gr;
                     } else {
                         float mm = m[p], vv = v[p];
-                        const float nv = RLC_ADAM_SMALL(th[p], gr, mm, vv, alpha);
+                        const float nv = astep_small(th[p], gr, mm, vv, alpha);
                         m[p] = mm; v[p] = vv; th[p] = nv;
                         if (tap) tap[p] = gr;
                         if (tt) tt[p] = polyak(tt[p], nv, tau);
@@ -866,7 +877,8 @@ struct Blk {
     struct WgPre { f32x4 w[4], m[4], v[4], t[4]; };
 
     // GONLY: as in trunk_grad_adam -- the gradient tiles go to `tapp` (not null), nothing else is read or written.
-    template <int NS, int NE, int BIT = -1, bool GONLY = false>
+    // NOPOL: the matrix has no target copy (Wt unused): no target loads, no Polyak stores.
+    template <int NS, int NE, int BIT = -1, bool GONLY = false, bool NOPOL = false>
     __device__ __forceinline__ void wgrad_adam(const lds_f32* seed /* LDS [MB][NS] */, const lds_f32* E /* LDS [MB][NE] or null */,
                                                int N, float* Wp, float* mp, float* vp,
                                                float alpha, float* tapp, float* Wt, float tau,
@@ -899,7 +911,7 @@ struct Blk {
                 P.w[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
                 P.m[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
                 P.v[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
-                P.t[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
+                if constexpr (!NOPOL) P.t[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
             }
         };
         auto run = [&](const WgPre& P, int idx, auto mcc_tag) {
@@ -983,16 +995,16 @@ struct Blk {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float mm = nm[r], vv = nv[r];
-                    nw[r] = adam_step_fast(P.w[q][r], acc[q][r], mm, vv, alpha);
+                    nw[r] = astep_big(P.w[q][r], acc[q][r], mm, vv, alpha);
                     nm[r] = mm; nv[r] = vv;
-                    nt[r] = polyak(P.t[q][r], nw[r], tau);
+                    if constexpr (!NOPOL) nt[r] = polyak(P.t[q][r], nw[r], tau);
                 }
                 if (q < nq && kp < H1 && n4ok) {
                     const size_t p = (((size_t)(m0 + q) * NT + t) << 8) + lane4;
                     *reinterpret_cast<f32x4*>(&mp[p]) = nm;
                     *reinterpret_cast<f32x4*>(&vp[p]) = nv;
                     *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
-                    *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
+                    if constexpr (!NOPOL) *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
                     if (tapp) *reinterpret_cast<f32x4*>(&tapp[p]) = acc[q];
                 }
             }
@@ -1058,10 +1070,10 @@ struct Blk {
                         const size_t p = rlc_blk_index(((H1 + 15) & ~15) + j, n, N);   // first extra block row + j
                         if constexpr (GONLY) { tapp[p] = gr; continue; }
                         float mm = mp[p], vv = vp[p];
-                        const float nv = RLC_ADAM_SMALL(Wp[p], gr, mm, vv, alpha);
+                        const float nv = astep_small(Wp[p], gr, mm, vv, alpha);
                         mp[p] = mm; vp[p] = vv; Wp[p] = nv;
                         if (tapp) tapp[p] = gr;
-                        Wt[p] = polyak(Wt[p], nv, tau);
+                        if constexpr (!NOPOL) Wt[p] = polyak(Wt[p], nv, tau);
                     }
                 }
             }
@@ -1069,6 +1081,15 @@ struct Blk {
         sub_stamp(24);
     }
 
+    // the same through this block's Adam form (TADAM: torch's step)
+    __device__ __forceinline__ void adam_scalar_m(float* th, float* m, float* v, float* tt, float* tap, int p, float gr,
+                                                  float alpha, float tau) const {
+        float mm = m[p], vv = v[p];
+        const float nv = astep_small(th[p], gr, mm, vv, alpha);
+        m[p] = mm; v[p] = vv; th[p] = nv;
+        if (tap) tap[p] = gr;
+        if (tt) tt[p] = polyak(tt[p], nv, tau);
+    }
     // Adam (+ Polyak) on one scalar parameter by the calling lane
     __device__ __forceinline__ static void adam_scalar(float* th, float* m, float* v, float* tt, float* tap, int p,
                                                        float gr, float alpha, float tau) {

@@ -47,6 +47,13 @@ int rlc_kl_create(const rlc_kl_config* cfg, rlc_handle** out) {
     RlcSacDev& dv = h->sac;
     dv.d = rlc_sac_make_dims(cfg->state_dim, cfg->action_dim, cfg->actor_l1_dim, cfg->actor_l2_dim, cfg->critic_l1_dim,
                              cfg->critic_l2_dim, cfg->batch_size, 0, 1);
+    // the tile-blocked weight layout goes with the MFMA kernel (the default whenever it supports the shape)
+    {
+        const bool integral_ = cfg->optim_type == RLC_KL_OPTIM_INTG || cfg->optim_type == RLC_KL_OPTIM_HARD_INTG;
+        if (rlc_kl_mfma_supported(dv.d, integral_ ? cfg->n_nodes : 0))
+            dv.d = rlc_sac_make_dims(cfg->state_dim, cfg->action_dim, cfg->actor_l1_dim, cfg->actor_l2_dim,
+                                     cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size, 1, 1);
+    }
     dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
     dv.clip_state = 0;   // the networks never apply the input normaliser they are handed (reversekl_network.py:43)
@@ -108,6 +115,23 @@ int rlc_kl_get_step(rlc_handle* h, int32_t agent, int32_t* step) {
     RLC_REQUIRE(step, "null step");
     RLC_HIP(hipMemcpyAsync(step, h->sac.kl_step + agent, sizeof(int), hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int rlc_kl_set_kernel(rlc_handle* h, int32_t variant) {
+    RLC_REQUIRE(h, "null handle");
+    RLC_NEED_KL(h);
+    RLC_REQUIRE(variant >= 0 && variant <= 2, "kernel variant must be 0 (auto), 1 (generic) or 2 (mfma)");
+    RLC_REQUIRE(variant != 2 || rlc_kl_mfma_supported(h->sac.d, h->sac.kl_nodes),
+                "MFMA KL kernel does not support these dimensions");
+    h->variant = variant;
+    return rlc_h_sac_relayout(h, rlc_h_kl_variant(h) == 2 ? 1 : 0);
+}
+
+int rlc_kl_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {
+    RLC_REQUIRE(h && variant_in_use, "null argument");
+    RLC_NEED_KL(h);
+    *variant_in_use = rlc_h_kl_variant(h);
     return 0;
 }
 

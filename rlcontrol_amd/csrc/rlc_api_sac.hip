@@ -38,7 +38,7 @@ int sac_relayout(rlc_handle* h, int blocked) {
     if (h->sac.d.blocked == blocked) return 0;
     if (rlc_h_use_device(h)) return 1;
     const RlcSacDims od = h->sac.d;
-    const RlcSacDims nd = rlc_sac_make_dims(od.S, od.A, od.L1A, od.L2A, od.L1C, od.L2C, od.B, blocked);
+    const RlcSacDims nd = rlc_sac_make_dims(od.S, od.A, od.L1A, od.L2A, od.L1C, od.L2C, od.B, blocked, od.qcat);
     const size_t NA = h->sac.n_agents, PP = od.Ppad;
     std::vector<float> dev(NA * PP), compact(od.P), out(NA * PP);
     for (int which = 0; which < 4; which++) {
@@ -72,10 +72,14 @@ int upload_eps(rlc_handle* h, const float* eps, size_t count, const float** out_
 
 }  // namespace
 
+int rlc_h_sac_relayout(rlc_handle* h, int blocked) { return sac_relayout(h, blocked); }
+
 int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
                             const float* eps_dev, const RlcSacRollout* rollout) {
     if (h->algo == RLC_ALGO_KL) {
         RLC_REQUIRE(!rollout, "the on-device experiment loop does not implement the KL agents");
+        if (rlc_h_kl_variant(h) == 2)
+            return rlc_launch_kl_update_mfma(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st);
         return rlc_launch_kl_update(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st);
     }
     if (rlc_h_sac_variant(h) == 2) {

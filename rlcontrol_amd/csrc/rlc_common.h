@@ -388,6 +388,13 @@ __device__ __forceinline__ float adam_step_fast(float var, float g, float& m, fl
     return var - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + 1e-8f);
 }
 
+__device__ __forceinline__ float adam_step_fast_eps(float var, float g, float& m, float& v, float alpha, float eps) {
+#pragma clang fp contract(off)
+    m += (g - m) * (1.0f - 0.9f);
+    v += (g * g - v) * (1.0f - 0.999f);
+    return var - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + eps);
+}
+
 __device__ __forceinline__ float adam_alpha(float lr, float b1p, float b2p) {
     return lr * sqrtf(1.0f - b2p) / (1.0f - b1p);
 }

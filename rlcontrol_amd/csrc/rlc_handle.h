@@ -46,6 +46,10 @@ inline int rlc_h_sac_variant(const rlc_handle* h) {
     if (h->variant == 1 || h->variant == 2) return h->variant;
     return rlc_sac_mfma_supported(h->sac.d) ? 2 : 1;
 }
+inline int rlc_h_kl_variant(const rlc_handle* h) {
+    if (h->variant == 1 || h->variant == 2) return h->variant;
+    return rlc_kl_mfma_supported(h->sac.d, h->sac.kl_nodes) ? 2 : 1;
+}
 inline int rlc_h_naf_variant(const rlc_handle* h) {
     if (h->variant == 1 || h->variant == 2) return h->variant;
     return rlc_naf_mfma_supported(h->naf.d) ? 2 : 1;
@@ -56,6 +60,8 @@ int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int 
 int rlc_h_naf_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
                             const struct RlcNafRollout* rollout);
 
+// re-pack the four per-agent blobs of an RlcSacDev handle between the row-major and the tile-blocked layout
+int rlc_h_sac_relayout(rlc_handle* h, int blocked);
 // bodies shared by the rlc_sac_* and rlc_kl_* entry points (rlc_api_sac.hip); algo = RLC_ALGO_SAC or RLC_ALGO_KL
 extern "C" {
 int rlc_sacfam_param_count(int algo, const rlc_handle* h, int64_t* out_p);

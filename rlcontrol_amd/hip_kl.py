@@ -140,6 +140,16 @@ class KLPopulation(Population):
         check(self._lib.rlc_kl_update_batch(self._h, int(agent), ctypes.c_int32(n), dptr(s), dptr(a), dptr(s2), dptr(r),
                                             dptr(g), fptr(e) if e is not None else None))
 
+    KERNEL = {"auto": 0, "generic": 1, "mfma": 2}
+
+    def set_kernel(self, name):
+        check(self._lib.rlc_kl_set_kernel(self._h, self.KERNEL[name]))
+
+    def kernel_in_use(self):
+        out = ctypes.c_int32(0)
+        check(self._lib.rlc_kl_get_kernel(self._h, ctypes.byref(out)))
+        return {v: k for k, v in self.KERNEL.items()}[out.value]
+
     def enable_grad_taps(self, on=True):
         check(self._lib.rlc_kl_enable_grad_taps(self._h, 1 if on else 0))
 

@@ -40,9 +40,10 @@ def main():
             np.full(n, 0.99))
     out = {"agents": a.agents, "batch": a.batch, "n_param": a.n_param, "records_per_agent": n,
            "flop_per_update": flop_per_update(a.batch, a.n_param - 2)}
-    for kind in ("reverse", "forward"):
+    for kind, kernel in (("reverse", "mfma"), ("forward", "mfma"), ("reverse", "generic")):
         pop = hip_kl.KLPopulation(kind, a.agents, *DIMS, a.batch, n, 0.01, 2.0, 1e-3, 1e-3, 0.1,
                                   seeds=np.arange(a.agents) + 1, n_param=a.n_param)
+        pop.set_kernel(kernel)
         for i in range(a.agents):
             pop.set_params(i, hip_kl.init_params(*DIMS, i))
             pop.replay_add_batch(i, *data)
@@ -54,9 +55,11 @@ def main():
         ms = pop.timer_end()
         rate = a.agents * a.updates * 5 / (ms * 1e-3)
         assert np.all(np.isfinite(pop.get_blob(0, "theta")))
-        out[kind] = {"updates_per_s": rate, "ms_per_launch": ms / 5, "updates_per_launch": a.updates,
-                     "tflops": rate * out["flop_per_update"] / 1e12}
-        print("%sKL: %.0f updates/s (%d agents), %.2f TFLOP/s" % (kind, rate, a.agents, out[kind]["tflops"]), flush=True)
+        out[kind + "_" + kernel] = {"updates_per_s": rate, "ms_per_launch": ms / 5, "updates_per_launch": a.updates,
+                                    "tflops": rate * out["flop_per_update"] / 1e12,
+                                    "frac_of_fp32_matrix_peak": rate * out["flop_per_update"] / 157.3e12}
+        print("%sKL %s: %.0f updates/s (%d agents), %.2f TFLOP/s" % (kind, kernel, rate, a.agents,
+                                                                    out[kind + "_" + kernel]["tflops"]), flush=True)
         pop.close()
     if a.cpu_updates > 0:
         import torch

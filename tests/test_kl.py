@@ -165,21 +165,36 @@ def test_oracle_targets_and_polyak_follow_the_reference_lines():
 
 
 # ------------------------------------------------------------------------------------------ GPU
-def _pop(kind, dims, B, optim="intg", qup="non_sac", n_agents=1, alpha=0.3, cap=2048, n_param=64, pi_lr=1e-3, qv_lr=1e-2):
+KERNELS = ["generic", "mfma"]
+
+
+def _pop(kind, dims, B, optim="intg", qup="non_sac", n_agents=1, alpha=0.3, cap=2048, n_param=64, pi_lr=1e-3, qv_lr=1e-2,
+         kernel="auto"):
     from rlcontrol_amd.hip_kl import KLPopulation
+    from rlcontrol_amd._lib import RlcError
     S, A, L1A, L2A, L1C, L2C = dims
-    return KLPopulation(kind, n_agents, S, A, L1A, L2A, L1C, L2C, B, cap, 0.01, 2.0, pi_lr, qv_lr, alpha,
-                        seeds=list(range(5, 5 + n_agents)), n_param=n_param, optim_type=optim, q_update_type=qup)
+    pop = KLPopulation(kind, n_agents, S, A, L1A, L2A, L1C, L2C, B, cap, 0.01, 2.0, pi_lr, qv_lr, alpha,
+                       seeds=list(range(5, 5 + n_agents)), n_param=n_param, optim_type=optim, q_update_type=qup)
+    if kernel != "auto":
+        try:
+            pop.set_kernel(kernel)
+        except RlcError:
+            pop.close()
+            pytest.skip("the %s kernel does not take this shape" % kernel)
+        assert pop.kernel_in_use() == kernel
+    return pop
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("kind,optim,qup", MODES)
-@pytest.mark.parametrize("dims,B,n_param", [(HEADLINE, 32, 64), ((5, 1, 64, 48, 40, 56), 17, 9), ((3, 1, 128, 128, 128, 128), 100, 33)])
-def test_kl_hip_update_matches_oracle(hip_lib, kind, optim, qup, dims, B, n_param):
+@pytest.mark.parametrize("dims,B,n_param", [(HEADLINE, 32, 64), ((5, 1, 64, 48, 40, 56), 17, 9), ((3, 1, 128, 128, 128, 128), 100, 33),
+                                            ((7, 1, 200, 160, 176, 144), 24, 130)])
+def test_kl_hip_update_matches_oracle(hip_lib, kind, optim, qup, dims, B, n_param, kernel):
     d = K.KlDims(*dims)
     rng = np.random.RandomState(3)
     th = _lively(d, K.init_params(d, 1), rng)
-    pop = _pop(kind, dims, B, optim, qup, n_param=n_param)
+    pop = _pop(kind, dims, B, optim, qup, n_param=n_param, kernel=kernel)
     pop.enable_grad_taps(True)
     pop.set_params(0, th)
     o = K.KLOracle(kind, d, th, 1e-3, 1e-2, 0.3, 0.01, 2.0, n_param, optim, qup)
@@ -198,16 +213,26 @@ def test_kl_hip_update_matches_oracle(hip_lib, kind, optim, qup, dims, B, n_para
             got = pop.last_tap(0, "grads")
             for n, (off, shp) in lay.items():
                 k = int(np.prod(shp))
-                assert _rel(got[off:off + k], t["grads"][off:off + k]) < 5e-5, n
-            # the first Adam step is lr * g / (|g| + eps): an element whose gradient is a cancelling sum near zero
-            # carries that sum's rounding into a step of up to lr, so theta is compared at 5e-5 of its range
-            assert _rel(pop.get_blob(0, "theta"), o.theta.numpy()) < 5e-5
+                # a one-element tensor (a head's bias) is a cancelling sum over the batch measured against itself
+                assert _rel(got[off:off + k], t["grads"][off:off + k]) < (5e-5 if k > 1 else 3e-4), n
+            # the first Adam step is lr * g / (|g| + eps): where |g| is a cancelling sum near zero, rounding turns into a
+            # step of up to lr -- parameters are compared where the step is well conditioned, and bounded elsewhere
+            got_th, want_th = pop.get_blob(0, "theta"), o.theta.numpy()
+            for n, (off, shp) in lay.items():
+                k = int(np.prod(shp))
+                lr = 1e-3 if n[0] == "p" else 1e-2
+                gref = np.abs(t["grads"][off:off + k])
+                solid = gref > 1e-3 * gref.max()
+                dth = np.abs(got_th[off:off + k].astype(np.float64) - want_th[off:off + k])
+                assert dth[solid].max() < 2e-3 * lr + 1e-7, n
+                assert dth.max() <= 1.05 * lr, n
             assert _rel(pop.get_blob(0, "adam_m"), o.m.numpy()) < 5e-5
             assert _rel(pop.get_blob(0, "adam_v"), o.v.numpy()) < 5e-5
             vo = lay["vW1"][0]
             assert _rel(pop.get_blob(0, "theta_target")[vo:], o.theta_t.numpy()[vo:]) < 1e-5
     assert pop.get_step(0) == 3
-    assert _rel(pop.get_blob(0, "theta"), o.theta.numpy()) < 2e-4
+    diff = np.abs(pop.get_blob(0, "theta").astype(np.float64) - o.theta.numpy())
+    assert np.quantile(diff, 0.995) < 5e-5 and diff.max() <= 3.2e-2, (np.quantile(diff, 0.995), diff.max())
     pop.close()
 
 
@@ -228,14 +253,15 @@ def _near_relu_kink(o, s, a, margin=1.5e-6):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("kind", K.KINDS)
-def test_kl_hip_at_reference_initialisation(hip_lib, kind):
+def test_kl_hip_at_reference_initialisation(hip_lib, kind, kernel):
     """the reference's own initialisation (output layers U(+-3e-3)) and its json's learning rates, a trajectory of
     fifteen updates (minibatches that sit on a ReLU kink are skipped, see _near_relu_kink)"""
     dims, B = HEADLINE, 32
     d = K.KlDims(*dims)
     th = K.init_params(d, 4)
-    pop = _pop(kind, dims, B, alpha=0.1, pi_lr=1e-3, qv_lr=1e-3)
+    pop = _pop(kind, dims, B, alpha=0.1, pi_lr=1e-3, qv_lr=1e-3, kernel=kernel)
     pop.set_params(0, th)
     o = K.KLOracle(kind, d, th, 1e-3, 1e-3, 0.1, 0.01, 2.0, 64)
     rng = np.random.RandomState(9)
@@ -255,14 +281,15 @@ def test_kl_hip_at_reference_initialisation(hip_lib, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("kind", K.KINDS)
-def test_kl_hip_replay_path_device_sampler_and_act(hip_lib, kind):
+def test_kl_hip_replay_path_device_sampler_and_act(hip_lib, kind, kernel):
     from oracle import philox
     from oracle.cpu_baseline import synthetic_pendulum_replay
     dims, B, N, NU = HEADLINE, 32, 2048, 3
     d = K.KlDims(*dims)
     rng = np.random.RandomState(1)
-    pop = _pop(kind, dims, B, n_agents=2, cap=N)            # seeds 5, 6
+    pop = _pop(kind, dims, B, n_agents=2, cap=N, kernel=kernel)            # seeds 5, 6
     ths = [_lively(d, K.init_params(d, 10 + i), rng) for i in range(2)]
     s, a, r, s2, g = synthetic_pendulum_replay(N, 0)
     for i in range(2):
@@ -352,3 +379,38 @@ def test_kl_dropin_agent_runs_on_pendulum(hip_lib, name):
     assert agent.network_manager.population.get_step(0) == 80 - 32        # learn() once the buffer exceeds the batch
     g1, g2 = agent.start(obs, False), agent.start(obs, False)
     assert np.array_equal(g1, g2)                    # evaluation uses the mean action
+
+
+@pytest.mark.gpu
+def test_kl_kernel_switch_repacks_weights_and_optimizer_state(hip_lib):
+    """generic <-> mfma changes the device layout (row-major <-> tile-blocked): blobs survive the round trip and the
+    two kernels continue the same trajectory to summation-order accuracy."""
+    dims, B = HEADLINE, 32
+    d = K.KlDims(*dims)
+    rng = np.random.RandomState(5)
+    th = _lively(d, K.init_params(d, 7), rng)
+    o = K.KLOracle("reverse", d, th, 1e-3, 1e-2, 0.3, 0.01, 2.0, 64)
+    pa, pb = _pop("reverse", dims, B, kernel="mfma"), _pop("reverse", dims, B, kernel="generic")
+    for p in (pa, pb):
+        p.set_params(0, th)
+    done = 0
+    while done < 4:
+        s, a, s2, r, g, eps = _batch(rng, B, 3)
+        if _near_relu_kink(o, s, a):
+            continue
+        o.update(s, a, s2, r, g, eps)
+        pa.update_batch(0, s, a, s2, r, g, eps=eps)
+        pb.update_batch(0, s, a, s2, r, g, eps=eps)
+        done += 1
+        if done == 2:                                # swap the kernels mid-trajectory
+            before = {w: pa.get_blob(0, w) for w in ("theta", "adam_m", "adam_v")}
+            pa.set_kernel("generic"); pb.set_kernel("mfma")
+            for w, v in before.items():
+                assert np.array_equal(pa.get_blob(0, w), v), w
+    lay, _ = d.layout()
+    vo = lay["vW1"][0]
+    for w in ("theta", "adam_m", "adam_v"):
+        assert _rel(pa.get_blob(0, w), pb.get_blob(0, w)) < 2e-4, w
+    assert _rel(pa.get_blob(0, "theta_target")[vo:], pb.get_blob(0, "theta_target")[vo:]) < 2e-4
+    assert _rel(pa.get_blob(0, "theta"), o.theta.numpy()) < 2e-4
+    pa.close(); pb.close()
