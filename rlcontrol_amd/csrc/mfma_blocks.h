@@ -1045,7 +1045,8 @@ struct Blk {
         // extra rows of a concat layer (rank-NE term): G[H1+j][n] = sum_b E[b][j] * D[b][n]; one N tile per
         // wave at a time
         if constexpr (NE > 0) {
-            for (int t = wave; t < NT; t += kWaves) {
+            // waves 4-7 carry six of the 52 tile chunks above, waves 0-3 seven: the extra rows go to waves 4-7 first
+            for (int t = (wave + 4) & 7; t < NT; t += kWaves) {
                 const int n = 16 * t + c;
                 const bool nok = n < N;
                 float wvn[NS];
