@@ -343,6 +343,10 @@ int rlc_ddpg_rollout_run(rlc_ddpg* h, int64_t n_steps, int64_t* out_total_steps)
  * (sample_for_eval "False"); the N(0,1) draws come from the agent's Philox stream */
 int rlc_sac_rollout_create(rlc_sac* h, const rlc_rollout_config* cfg);
 int rlc_sac_rollout_run(rlc_sac* h, int64_t n_steps, int64_t* out_total_steps);
+/* the same loop for a ReverseKL / ForwardKL population (agents/ReverseKL.py:31-81): training actions are samples
+ * tanh(mean + std*eps)*action_max of the current policy, evaluation uses tanh(mean)*action_max (sample_for_eval "False") */
+int rlc_kl_rollout_create(rlc_kl* h, const rlc_rollout_config* cfg);
+int rlc_kl_rollout_run(rlc_kl* h, int64_t n_steps, int64_t* out_total_steps);
 /* the same loop for a NAF population (agents/NAF.py:24-75): training actions are draws from
  * N(mu, noise_scale * pinv(L L^T)) clipped to the action bounds (naf_network.py:152-176; on the device
  * mu + sqrt(noise_scale) L^-T z with Philox normals z), evaluation uses the greedy action.

@@ -89,7 +89,11 @@ _SHARED_KEYS = {
                         "tau", "gamma", "warmup_steps", "norm_type", "exploration_policy", "sample_for_eval"),
     "NAF": ("l1_dim", "l2_dim", "batch_size", "buffer_size", "tau", "gamma", "warmup_steps", "norm_type",
             "exploration_policy"),
+    "ReverseKL": ("actor_l1_dim", "actor_l2_dim", "critic_l1_dim", "critic_l2_dim", "batch_size", "buffer_size", "tau",
+                  "gamma", "warmup_steps", "exploration_policy", "sample_for_eval", "N_param", "optim_type",
+                  "q_update_type", "use_true_q"),
 }
+_SHARED_KEYS["ForwardKL"] = _SHARED_KEYS["ReverseKL"]
 
 
 def _make_population(agent_name, members, arg_params):
@@ -101,6 +105,24 @@ def _make_population(agent_name, members, arg_params):
     # reported in the pickle's agent_params as if it had run (the reference applies layer / batch norm for those values,
     # agents/network/base_network.py:53-65)
     from rlcontrol_amd.agents.network.base_network_manager import check_norm_type
+    if agent_name in ("ReverseKL", "ForwardKL"):
+        # the torch networks of these agents never apply the normaliser they are handed (reversekl_network.py:43)
+        from rlcontrol_amd.hip_kl import KLPopulation, init_params
+        if c0.exploration_policy != 'none' or c0.sample_for_eval == "True" or c0.use_true_q == "True":
+            raise RuntimeError("the device loop implements the KL agents with exploration_policy 'none', "
+                               "sample_for_eval 'False' and use_true_q 'False' (the shipped jsons)")
+        pop = KLPopulation(
+            "reverse" if agent_name == "ReverseKL" else "forward", n_agents=len(members), state_dim=c0.state_dim,
+            action_dim=c0.action_dim, actor_l1_dim=c0.actor_l1_dim, actor_l2_dim=c0.actor_l2_dim,
+            critic_l1_dim=c0.critic_l1_dim, critic_l2_dim=c0.critic_l2_dim, batch_size=c0.batch_size,
+            buffer_size=int(c0.buffer_size), tau=c0.tau, action_max0=float(np.asarray(c0.action_max).reshape(-1)[0]),
+            pi_lr=[m[3].pi_lr for m in members], qf_vf_lr=[m[3].qf_vf_lr for m in members],
+            entropy_scale=[m[3].entropy_scale for m in members], seeds=seeds, n_param=c0.N_param,
+            optim_type=c0.optim_type, q_update_type=c0.q_update_type, device=device)
+        for i, m in enumerate(members):
+            pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.actor_l1_dim, c0.actor_l2_dim, c0.critic_l1_dim,
+                                          c0.critic_l2_dim, m[3].random_seed), init_target=True)
+        return pop
     check_norm_type(c0, agent_name + " --device_rollout",
                     ('input_norm',) if agent_name == "SoftActorCritic" else ('none', 'input_norm'))
     if agent_name == "DDPG":
@@ -158,7 +180,8 @@ def run_indices_on_device(indices, agent_json, env_json, env_params, arg_params,
     from rlcontrol_amd.device_experiment import DeviceExperiment
     agent_name = agent_json['agent']
     if agent_name not in _SHARED_KEYS:
-        raise RuntimeError("--device_rollout is built for the DDPG, SoftActorCritic and NAF agents (got %r)" % agent_name)
+        raise RuntimeError("--device_rollout is built for the DDPG, SoftActorCritic, NAF, ReverseKL and ForwardKL agents "
+                           "(got %r)" % agent_name)
     groups = OrderedDict()
     for index in indices:
         agent_params, total_num_sweeps = get_sweep_parameters(agent_json['sweeps'], index)

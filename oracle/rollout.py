@@ -216,6 +216,24 @@ class SacRolloutOracle(RolloutOracle):
                         np.array([r[4] for r in rows]), eps)
 
 
+class KlRolloutOracle(SacRolloutOracle):
+    """One ReverseKL / ForwardKL agent of the on-device loop: the step is SoftActorCritic's (sampled training action,
+    mean evaluation action, the same two Philox sub-streams for acting and minibatch draws) on the torch restatement
+    of the KL networks (oracle/kl_torch.py); the states enter unclipped."""
+
+    def __init__(self, kind, dims, theta, pi_lr, qv_lr, alpha, tau, amax0, n_param, seed, batch_size, buffer_size, gamma,
+                 warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes, optim_type="intg",
+                 q_update_type="non_sac"):
+        self._kl = (kind, pi_lr, qv_lr, alpha, amax0, n_param, optim_type, q_update_type)
+        RolloutOracle.__init__(self, dims, theta, 0.0, 0.0, tau, None, None, [-amax0], [amax0], seed, batch_size,
+                               buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes)
+
+    def _make_net(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state):
+        from .kl_torch import KLOracle
+        kind, pi_lr, qv_lr, alpha, amax0, n_param, optim_type, q_update_type = self._kl
+        return KLOracle(kind, dims, theta, pi_lr, qv_lr, alpha, tau, amax0, n_param, optim_type, q_update_type)
+
+
 class NafRolloutOracle(RolloutOracle):
     """One NAF agent of the on-device loop (naf_rollout_device.h): the training action is
     mu + sqrt(noise_scale) * L^-T z (a draw from N(mu, noise_scale (L L^T)^-1), naf_network.py:152-176) clipped to

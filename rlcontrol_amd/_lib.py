@@ -34,7 +34,7 @@ EXPORTS = (
     "rlc_naf_create", "rlc_naf_param_count", "rlc_naf_set_blob", "rlc_naf_get_blob", "rlc_naf_get_beta_powers",
     "rlc_naf_init_target", "rlc_naf_act", "rlc_naf_update", "rlc_naf_update_batch", "rlc_naf_last_tap",
     "rlc_naf_enable_grad_taps", "rlc_naf_set_kernel", "rlc_naf_get_kernel",
-    "rlc_ddpg_rollout_create", "rlc_ddpg_rollout_run", "rlc_sac_rollout_create", "rlc_sac_rollout_run",
+    "rlc_ddpg_rollout_create", "rlc_ddpg_rollout_run", "rlc_sac_rollout_create", "rlc_sac_rollout_run", "rlc_kl_rollout_create", "rlc_kl_rollout_run",
     "rlc_naf_rollout_create", "rlc_naf_rollout_run", "rlc_rollout_counts", "rlc_rollout_train_log",
     "rlc_rollout_eval_log", "rlc_rollout_observation",
 )

@@ -18,7 +18,7 @@
 // The input normaliser handed to the networks is never applied by them (reversekl_network.py:43): states enter raw.
 // r and gamma are cast to fp32 (torch.FloatTensor(reward_batch), reversekl_network.py:135-136).
 #include "generic_blocks.h"
-#include "sac_policy.h"
+#include "sac_rollout_device.h"
 #include "../../include/rlcontrol_hip.h"
 
 namespace {
@@ -30,6 +30,7 @@ struct KLds {
     long long* idx;
     int* pool;
     int* dups;
+    float* pol;       // scratch of the on-device training step (sac_rollout_device.h)
 };
 
 __host__ __device__ inline size_t klds_carve(const RlcSacDims& d, unsigned char* base, KLds* out) {
@@ -51,6 +52,7 @@ __host__ __device__ inline size_t klds_carve(const RlcSacDims& d, unsigned char*
     L.adam = (float*)take(sizeof(float) * 4);
     L.pool = (int*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     L.dups = (int*)take(sizeof(int) * 4);
+    L.pol = (float*)take(sizeof(float) * (sac_policy_lds_floats(d) + 4));
     if (out) *out = L;
     return off;
 }
@@ -60,7 +62,8 @@ __host__ __device__ inline int kl_chunk_rows(int rows) { return rows < 2048 ? ro
 
 __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, int first_agent, int n_updates,
                                                                  int source, const long long* host_idx,
-                                                                 const float* eps_in, int grad_taps) {
+                                                                 const float* eps_in, int grad_taps,
+                                                                 const RlcSacRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcSacDims d = dv.d;
     const int S = d.S, L1A = d.L1A, L2A = d.L2A, L1C = d.L1C, L2C = d.L2C, B = d.B, K = dv.kl_nodes;
@@ -95,6 +98,10 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
     const float invB = 1.0f / (float)B;
 
     for (int u = 0; u < n_updates; u++) {
+        if (rollout) {
+            // on-device experiment loop: one environment step first; update when learn() would run
+            if (!rlc_sac_train_step_device(rollout, agent, L.pol)) continue;
+        }
         // ---- sample + gather ----
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
@@ -348,14 +355,16 @@ size_t rlc_kl_scratch_floats(const RlcSacDims& d, int nodes) {
 }
 
 int rlc_launch_kl_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                         const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st) {
+                         const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
+                         const RlcSacRollout* rollout) {
     const size_t lds = klds_carve(dv.d, nullptr, nullptr);
     RLC_REQUIRE(dv.d.A == 1 && dv.d.qcat == 1, "the KL update kernel needs action_dim 1 and the input-concatenated Q layout");
     const bool integral = dv.kl_optim == RLC_KL_OPTIM_INTG || dv.kl_optim == RLC_KL_OPTIM_HARD_INTG;
     RLC_REQUIRE(!integral || dv.kl_nodes >= 1, "no quadrature nodes");
     RLC_REQUIRE(lds <= 64 * 1024, "KL kernel needs %zu B of LDS", lds);
+    RLC_REQUIRE(!(rollout && eps_dev), "the on-device loop draws its own eps");
     hipLaunchKernelGGL(rlc_kl_update_kernel, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates,
-                       source, idx_dev, eps_dev, grad_taps);
+                       source, idx_dev, eps_dev, grad_taps, rollout);
     RLC_HIP(hipGetLastError());
     return 0;
 }

@@ -14,8 +14,9 @@ bool rlc_kl_mfma_supported(const RlcSacDims& d, int nodes) {
 }
 
 int rlc_launch_kl_update_mfma(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                              const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st) {
+                              const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
+                              const RlcSacRollout* rollout) {
     RLC_REQUIRE(rlc_kl_mfma_supported(dv.d, dv.kl_nodes), "MFMA KL kernel does not support these dimensions");
     RLC_REQUIRE(dv.d.blocked, "the MFMA kernel reads tile-blocked weights (rlc_kl_set_kernel re-packs them)");
-    return kl_launch_t<2, 7>(dv, first_agent, n_agents, n_updates, source, idx_dev, eps_dev, grad_taps, st);
+    return kl_launch_t<2, 7>(dv, first_agent, n_agents, n_updates, source, idx_dev, eps_dev, grad_taps, st, rollout);
 }

@@ -21,7 +21,7 @@
 // Supported: action_dim 1, S <= 7, widths multiples of 4 in [16, 256], B <= 32, K <= 256 nodes, LDS <= 160 KiB.
 #pragma once
 #include "mfma_blocks.h"
-#include "sac_policy.h"
+#include "sac_rollout_device.h"
 #include "sac_common.h"
 
 namespace {
@@ -109,7 +109,8 @@ __device__ __forceinline__ float kl_wave_sum(float v) {
 template <int MT, int MTQ>
 __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev dv, int first_agent, int n_updates,
                                                                       int source, const long long* host_idx,
-                                                                      const float* eps_in, int grad_taps) {
+                                                                      const float* eps_in, int grad_taps,
+                                                                      const RlcSacRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using U = Blk<MT, KL_NTW, KL_MSTRIDE, true, true>;      // the three small networks: LERP target update, torch Adam
     using UQ = Blk<MTQ, KL_NTW, KL_MSTRIDE, true, true>;    // the node passes (forward only)
@@ -163,6 +164,10 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
     f32x4 acc[MT][NTW];
     for (int upd = 0; upd < n_updates; upd++) {
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));     // see ddpg_mfma_kernel.h
+        if (rollout) {
+            // on-device experiment loop: one environment step first (hbuf is free here); update when learn() would run
+            if (!rlc_sac_train_step_device(rollout, agent, (float*)L.hbuf)) continue;
+        }
         // ================= sample + gather =================
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
 
 template <int MT, int MTQ>
 int kl_launch_t(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
-                const float* eps_dev, int grad_taps, hipStream_t st) {
+                const float* eps_dev, int grad_taps, hipStream_t st, const RlcSacRollout* rollout) {
     const size_t lds = ksmem_carve(dv.d, MT, MTQ, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "MFMA KL kernel needs %zu B of LDS (> 160 KiB)", lds);
     auto kern = rlc_kl_update_mfma_kernel<MT, MTQ>;
@@ -603,8 +608,9 @@ int kl_launch_t(const RlcSacDev& dv, int first_agent, int n_agents, int n_update
         RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    RLC_REQUIRE(!(rollout && eps_dev), "the on-device loop draws its own eps");
     hipLaunchKernelGGL(kern, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates, source, idx_dev, eps_dev,
-                       grad_taps);
+                       grad_taps, rollout);
     RLC_HIP(hipGetLastError());
     return 0;
 }

@@ -76,9 +76,8 @@ int rlc_ddpg_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
     return 0;
 }
 
-int rlc_sac_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
-    RLC_REQUIRE(h && cfg, "null argument");
-    RLC_REQUIRE(h->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population");
+// SoftActorCritic and the KL agents share the device view (RlcSacDev) and the train step (sac_rollout_device.h)
+static int sacfam_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
     if (rollout_alloc(h, cfg)) return 1;
     if (rlc_h_malloc(h, &h->sac_rollout_dev, 1)) return 1;
     RlcSacRollout ro;
@@ -88,6 +87,18 @@ int rlc_sac_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
     RLC_HIP(hipStreamSynchronize(h->st));
     h->has_env = true;
     return 0;
+}
+
+int rlc_sac_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
+    RLC_REQUIRE(h && cfg, "null argument");
+    RLC_REQUIRE(h->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population");
+    return sacfam_rollout_create(h, cfg);
+}
+
+int rlc_kl_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
+    RLC_REQUIRE(h && cfg, "null argument");
+    RLC_REQUIRE(h->algo == RLC_ALGO_KL, "handle is not a ReverseKL / ForwardKL population");
+    return sacfam_rollout_create(h, cfg);
 }
 
 int rlc_naf_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg, const float* noise_scale) {
@@ -115,7 +126,7 @@ int rlc_naf_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg, const f
 static int rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
     if (rlc_h_use_device(h)) return 1;
     RLC_REQUIRE(n_steps >= 0, "negative n_steps");
-    const bool sac = h->algo == RLC_ALGO_SAC, naf = h->algo == RLC_ALGO_NAF;
+    const bool sac = h->algo == RLC_ALGO_SAC || h->algo == RLC_ALGO_KL, naf = h->algo == RLC_ALGO_NAF;
     auto eval_now = [&]() -> int {
         if (h->env.eval_episodes > 0) {
             const int rc = sac ? rlc_launch_sac_eval(h->sac, h->env, (int)h->ro_evals, h->st)
@@ -173,6 +184,12 @@ int rlc_ddpg_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_step
 int rlc_sac_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
     RLC_NEED_ENV(h);
     RLC_REQUIRE(h->algo == RLC_ALGO_SAC, "handle is not a SoftActorCritic population");
+    return rollout_run(h, n_steps, out_total_steps);
+}
+
+int rlc_kl_rollout_run(rlc_handle* h, int64_t n_steps, int64_t* out_total_steps) {
+    RLC_NEED_ENV(h);
+    RLC_REQUIRE(h->algo == RLC_ALGO_KL, "handle is not a ReverseKL / ForwardKL population");
     return rollout_run(h, n_steps, out_total_steps);
 }
 

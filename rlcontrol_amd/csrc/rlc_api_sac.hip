@@ -77,10 +77,10 @@ int rlc_h_sac_relayout(rlc_handle* h, int blocked) { return sac_relayout(h, bloc
 int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev,
                             const float* eps_dev, const RlcSacRollout* rollout) {
     if (h->algo == RLC_ALGO_KL) {
-        RLC_REQUIRE(!rollout, "the on-device experiment loop does not implement the KL agents");
         if (rlc_h_kl_variant(h) == 2)
-            return rlc_launch_kl_update_mfma(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st);
-        return rlc_launch_kl_update(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st);
+            return rlc_launch_kl_update_mfma(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st,
+                                             rollout);
+        return rlc_launch_kl_update(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st, rollout);
     }
     if (rlc_h_sac_variant(h) == 2) {
         RLC_REQUIRE(rlc_sac_mfma_supported(h->sac.d), "MFMA SAC kernel does not support these dimensions");

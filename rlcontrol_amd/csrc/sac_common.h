@@ -85,10 +85,12 @@ int rlc_launch_sac_update_mfma(const RlcSacDev& dv, int first_agent, int n_agent
 // ReverseKL / ForwardKL fused update and acting (kl_generic.hip); same argument meaning as the SAC launches
 size_t rlc_kl_scratch_floats(const RlcSacDims& d, int nodes);
 int rlc_launch_kl_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                         const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st);
+                         const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
+                         const RlcSacRollout* rollout = nullptr);
 bool rlc_kl_mfma_supported(const RlcSacDims& d, int nodes);
 int rlc_launch_kl_update_mfma(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,
-                              const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st);
+                              const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
+                              const RlcSacRollout* rollout = nullptr);
 int rlc_launch_kl_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
                       int sample, float* out_dev, hipStream_t st);
 int rlc_launch_sac_eval(const RlcSacDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);

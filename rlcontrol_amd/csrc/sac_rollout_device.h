@@ -3,7 +3,8 @@
 // the current policy (agents/SoftActorCritic.py:55-72: exploration_policy 'none', the sample IS the exploration)
 // -> env.step -> BaseAgent.update's insert rule -> learn gate.  There is no noise state to reset (quirk Q8 does
 // not apply).  The N(0,1) draws of acting and of the minibatch share the agent's Philox stream counter, as in the
-// host-driven device path.
+// host-driven device path.  The ReverseKL / ForwardKL populations (kl_generic.hip, kl_mfma_kernel.h) take the same step:
+// their handle is an RlcSacDev too (no state clip, clamped log_std).
 #pragma once
 #include "sac_policy.h"
 #include "rollout_env.h"
@@ -33,7 +34,7 @@ __device__ __noinline__ int rlc_sac_train_step_device(const RlcSacRollout* ro, i
     }
     for (int i = tid; i < S; i += nthr) L.x[i] = rlc_clip_scalar((float)obs[i], dv.clip_state, dv.smin0, dv.smax0);
     if (tid < A) L.eps[tid] = sac_act_eps(dv.rep.seed[agent], dv.noise_ctr[agent], tid);
-    sac_policy_forward(d, th, L, dv.amax0, 1);
+    sac_policy_forward(d, th, L, dv.amax0, 1, dv.kl_kind != 0);       // the KL agents clamp log_std, SAC squashes it
     if (tid == 0) {
         dv.noise_ctr[agent] += 1;
         *learn_flag = rlc_env_advance_store(dv.rep, env, agent, L.out);

@@ -47,7 +47,7 @@ class DeviceExperiment(object):
         cfg.gamma = float(gamma)
         self._max_ep = int(max_train_episodes)
         kind = type(population).__name__
-        self._prefix = {"SACPopulation": "rlc_sac", "NAFPopulation": "rlc_naf"}.get(kind, "rlc_ddpg")
+        self._prefix = {"SACPopulation": "rlc_sac", "NAFPopulation": "rlc_naf", "KLPopulation": "rlc_kl"}.get(kind, "rlc_ddpg")
         create = getattr(population._lib, self._prefix + "_rollout_create")
         if self._prefix == "rlc_naf":
             if noise_scale is None:

@@ -316,3 +316,73 @@ def test_naf_rollout_matches_cpu_restatement(hip_lib, noise):
         th = pop.get_blob(a, "theta")
         assert np.max(np.abs(th - orc.net.theta)) < 5e-3 * np.max(np.abs(orc.net.theta))
     pop.close()
+
+
+@pytest.mark.parametrize("kind,kernel", [("reverse", "mfma"), ("forward", "mfma"), ("reverse", "generic")])
+def test_kl_rollout_matches_cpu_restatement(hip_lib, kind, kernel):
+    """The on-device loop for a ReverseKL / ForwardKL population (the SoftActorCritic train step on the KL kernels)
+    against oracle/rollout.py's KlRolloutOracle (torch restatement) on the same Philox streams."""
+    from oracle.kl_torch import KlDims, init_params
+    from oracle.rollout import KlRolloutOracle
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    from rlcontrol_amd.hip_kl import KLPopulation
+    dims, B, n_param = (3, 1, 32, 32, 32, 32), 16, 18
+    seeds, pi_lr, qv_lr, alpha = [21, 99999999999], [1e-3, 5e-4], [1e-3, 2e-3], [0.2, 0.05]
+    pop = KLPopulation(kind, 2, *dims, B, 4096, 0.01, 2.0, pi_lr, qv_lr, alpha, seeds=seeds, n_param=n_param)
+    pop.set_kernel(kernel)
+    d = KlDims(*dims)
+    thetas = [init_params(d, 300 + i) for i in range(2)]
+    for i in range(2):
+        pop.set_params(i, thetas[i], init_target=True)
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00009, "EpisodeSteps": 25,
+           "EvalIntervalMilSteps": 0.00004, "EvalEpisodes": 2}
+    exp = DeviceExperiment(pop, env, gamma=0.99, warmup_steps=0)
+    assert exp.advance(37) == 37
+    exp.advance(1000)
+    assert exp.total_steps == 90
+    res = exp.results()
+    for a in range(2):
+        orc = KlRolloutOracle(kind, d, thetas[a], pi_lr[a], qv_lr[a], alpha[a], 0.01, 2.0, n_param, seeds[a], B, 4096, 0.99,
+                              0, 25, 90, 40, 2).run()
+        tr, er, tl, el, ts, _, _, n_started, tc = res[a]
+        assert tl == orc.train_len == [25] * 3 and tc == orc.train_cum == [25, 50, 75]
+        assert ts == orc.timesteps_at_eval == [0, 40, 80] and el == orc.eval_len and n_started == 4
+        assert pop.replay_size(a) == len(orc.replay) == 90 - 3
+        assert pop.get_step(a) == orc.net.step == orc.n_updates
+        s, act, r, s2, g = pop.replay_gather(a, np.arange(87))
+        os_ = np.array([t[0] for t in orc.replay]); oa = np.array([t[1] for t in orc.replay])
+        pre = B + 1
+        assert np.allclose(s[:pre], os_[:pre], atol=2e-6) and np.allclose(act[:pre], oa[:pre], atol=5e-6)
+        assert np.allclose(s, os_, atol=5e-3) and np.allclose(act, oa, atol=5e-3)
+        assert np.allclose(er[0], orc.eval_ret[0], rtol=1e-5, atol=1e-4)      # evaluation 0: initial weights, mean action
+        assert np.allclose(er, orc.eval_ret, rtol=5e-3, atol=5e-2)
+        th = pop.get_blob(a, "theta")
+        assert np.max(np.abs(th - orc.net.theta.numpy())) < 5e-3 * np.max(np.abs(orc.net.theta.numpy()))
+    pop.close()
+
+
+def test_main_device_rollout_kl_pickle(hip_lib, tmp_path):
+    """main.py --device_rollout with the ForwardKL agent: per-agent learning rates / entropy scale from the sweep."""
+    import json
+    import pickle
+    import main as drv
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00012, "EpisodeSteps": 50,
+           "EvalIntervalMilSteps": 0.00005, "EvalEpisodes": 2}
+    agent = {"agent": "ForwardKL",
+             "sweeps": {"norm_type": ["input_norm"], "exploration_policy": ["none"], "actor_l1_dim": [32],
+                        "actor_l2_dim": [32], "critic_l1_dim": [32], "critic_l2_dim": [32], "pi_lr": [1e-3],
+                        "qf_vf_lr": [1e-3], "sample_for_eval": ["False"], "use_true_q": ["False"],
+                        "entropy_scale": [0.1, 0.01], "l_param": [6], "N_param": [16], "optim_type": ["intg"],
+                        "q_update_type": ["non_sac"], "batch_size": [16], "buffer_size": [1000]}}
+    ej, aj = tmp_path / "Pendulum-v0.json", tmp_path / "forward_kl.json"
+    ej.write_text(json.dumps(env)); aj.write_text(json.dumps(agent))
+    drv.main(["--env_json", str(ej), "--agent_json", str(aj), "--indices", "0", "1", "4", "--save_dir", str(tmp_path),
+              "--device_rollout", "--quiet"])
+    with open(tmp_path / "Pendulum-v0_forward_klresults" / "data_0_1_4.pkl", "rb") as f:
+        data = pickle.load(f)
+    assert sorted(data["experiment_data"]) == [0, 1]
+    assert [r["random_seed"] for r in data["experiment_data"][0]["runs"]] == [0, 1]
+    assert data["experiment_data"][1]["agent_params"]["entropy_scale"] == 0.01
+    run = data["experiment_data"][1]["runs"][1]
+    assert run["eval_episode_rewards"].shape == (3, 2) and run["timesteps_at_eval"].tolist() == [0, 50, 100]
+    assert run["train_episode_steps"].tolist() == [50, 50] and np.isfinite(run["eval_episode_rewards"]).all()
