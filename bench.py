@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--split", type=int, default=1,
                     help="latency mode: every agent's minibatch over this many CUs (rlc_ddpg_set_split; use with --agents 1..32)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend of the N > 1 run (nccl = RCCL)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of the N > 1 path where fewer GPUs than ranks exist: rank r uses GPU r %% n_gpus "
+                         "(needs --backend gloo; the value is then NOT a scaling measurement and says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="skip the SAC / NAF sub-records")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -312,6 +315,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.share_gpu:
+        if args.backend == "nccl":
+            raise SystemExit("--share-gpu puts several ranks on one GPU: RCCL cannot do that, use --backend gloo")
+        local_rank = local_rank % max(1, torch.cuda.device_count())      # device_count() does not initialise the GPU
     torch.cuda.set_device(local_rank)          # before any other GPU call; no re-exec anywhere in this file
     dist = None
     if world > 1:
@@ -369,7 +376,9 @@ def main():
                        "agents_per_gpu": NA, "updates_per_step": U, "kernel": kernel,
                        "updates_timed_per_agent": U * args.steps, "updates_warmup_per_agent": U * args.warmup,
                        "per_gpu_value": NA * U * args.steps / dt_max,
-                       "parallelism": "independent seeds x%d per GPU, x%d GPUs" % (NA, world),
+                       "parallelism": ("independent seeds x%d per rank, x%d ranks SHARING the GPUs present (rehearsal, not a "
+                                       "scaling measurement)" if args.share_gpu else
+                                       "independent seeds x%d per GPU, x%d GPUs") % (NA, world),
                        "per_rank_result": gathered},
             "roofline": roof,
             "roofline_hbm": roof_hbm,
