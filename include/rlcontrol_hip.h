@@ -159,7 +159,9 @@ int rlc_ddpg_enable_grad_taps(rlc_ddpg* h, int32_t on);
  * (agents/SoftActorCritic.py:16-53, agents/network/sac_network.py:10-45; jsonfiles/agent/sac.json).
  * Parameter blob (P floats), variable creation order under 'main' (sac_network.py:152-172):
  *   pi: W1[S][L1a] b1 W2[L1a][L2a] b2 Wm[L2a][A] bm Ws[L2a][A] bs | qf: W1[S][L1c] b1 W2[L1c+A][L2c] b2 W3[L2c] b3 |
- *   vf: W1[S][L1c] b1 W2[L1c][L2c] b2 W3[L2c] b3.      blob selector: 0 theta, 1 target, 2 Adam m, 3 Adam v. */
+ *   vf: W1[S][L1c] b1 W2[L1c][L2c] b2 W3[L2c] b3.      blob selector: 0 theta, 1 target, 2 Adam m, 3 Adam v.
+ * With norm_type 'layer' every hidden layer is followed by its layer-norm beta[width] gamma[width]:
+ *   pi: W1 b1 beta1 gamma1 W2 b2 beta2 gamma2 Wm bm Ws bs | qf: W1 b1 beta1 gamma1 W2 b2 beta2 gamma2 W3 b3 | vf likewise. */
 typedef struct rlc_sac_config {
     int32_t device, n_agents, state_dim, action_dim;
     int32_t actor_l1_dim, actor_l2_dim, critic_l1_dim, critic_l2_dim;   /* jsonfiles/agent/sac.json:9-12 */
@@ -173,6 +175,11 @@ typedef struct rlc_sac_config {
     const float* qf_vf_lr;       /* [n_agents] */
     const float* entropy_scale;  /* [n_agents] */
     const uint64_t* seed;        /* [n_agents] Philox keys (sampler, eps) */
+    int32_t norm_type;           /* RLC_NORM_NONE ('none' / 'input_norm': activation only) or RLC_NORM_LAYER ('layer':
+                                  * tf.contrib.layers.layer_norm before every hidden relu of pi, qf and vf,
+                                  * base_network.py:53-56; every hidden layer then adds beta, gamma behind its bias in the
+                                  * blob).  'batch' is not implemented: create fails. */
+    int32_t reserved0;
 } rlc_sac_config;
 
 int rlc_sac_create(const rlc_sac_config* cfg, rlc_sac** out);

@@ -124,7 +124,7 @@ def _make_population(agent_name, members, arg_params):
                                           c0.critic_l2_dim, m[3].random_seed), init_target=True)
         return pop
     check_norm_type(c0, agent_name + " --device_rollout",
-                    ('input_norm',) if agent_name == "SoftActorCritic" else ('none', 'input_norm'))
+                    ('input_norm', 'layer') if agent_name == "SoftActorCritic" else ('none', 'input_norm'))
     if agent_name == "DDPG":
         from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
         if c0.exploration_policy != 'ou_noise':
@@ -168,10 +168,10 @@ def _make_population(agent_name, members, arg_params):
         state_min0=float(np.asarray(c0.state_min).reshape(-1)[0]), state_max0=float(np.asarray(c0.state_max).reshape(-1)[0]),
         action_max0=float(np.asarray(c0.action_max).reshape(-1)[0]), pi_lr=[m[3].pi_lr for m in members],
         qf_vf_lr=[m[3].qf_vf_lr for m in members], entropy_scale=[m[3].entropy_scale for m in members], seeds=seeds,
-        clip_state=True, device=device)
+        clip_state=True, device=device, norm_type=c0.norm_type)
     for i, m in enumerate(members):
         pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.actor_l1_dim, c0.actor_l2_dim, c0.critic_l1_dim,
-                                      c0.critic_l2_dim, m[3].random_seed), init_target=True)
+                                      c0.critic_l2_dim, m[3].random_seed, c0.norm_type), init_target=True)
     return pop
 
 

@@ -72,6 +72,7 @@ class rlc_sac_config(ctypes.Structure):
         ("action_max0", ctypes.c_float),
         ("pi_lr", ctypes.POINTER(ctypes.c_float)), ("qf_vf_lr", ctypes.POINTER(ctypes.c_float)),
         ("entropy_scale", ctypes.POINTER(ctypes.c_float)), ("seed", ctypes.POINTER(ctypes.c_uint64)),
+        ("norm_type", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 

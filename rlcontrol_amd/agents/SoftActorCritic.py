@@ -24,7 +24,7 @@ class SoftActorCritic_Network_Manager(BaseNetwork_Manager):
         if config.norm_type == 'none':
             # the reference leaves `inputs` undefined in that case (quirk Q10, sac_network.py:175-178)
             raise ValueError("SoftActorCritic needs norm_type != 'none'")
-        check_norm_type(config, "SoftActorCritic", ('input_norm',))
+        check_norm_type(config, "SoftActorCritic", ('input_norm', 'layer'))
         self.population = SACPopulation(
             n_agents=1, state_dim=config.state_dim, action_dim=config.action_dim,
             actor_l1_dim=config.actor_l1_dim, actor_l2_dim=config.actor_l2_dim,
@@ -34,9 +34,10 @@ class SoftActorCritic_Network_Manager(BaseNetwork_Manager):
             state_max0=float(np.asarray(config.state_max).reshape(-1)[0]),
             action_max0=float(np.asarray(config.action_max).reshape(-1)[0]),
             pi_lr=config.pi_lr, qf_vf_lr=config.qf_vf_lr, entropy_scale=config.entropy_scale,
-            seeds=[np.uint64(config.random_seed)], clip_state=True, device=int(getattr(config, "device", 0)))
+            seeds=[np.uint64(config.random_seed)], clip_state=True, device=int(getattr(config, "device", 0)),
+            norm_type=config.norm_type)
         theta0 = init_params(config.state_dim, config.action_dim, config.actor_l1_dim, config.actor_l2_dim,
-                             config.critic_l1_dim, config.critic_l2_dim, config.random_seed)
+                             config.critic_l1_dim, config.critic_l2_dim, config.random_seed, config.norm_type)
         self.population.set_params(0, theta0, init_target=True)
 
     def device_replay(self):

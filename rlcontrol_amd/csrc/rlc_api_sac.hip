@@ -38,7 +38,7 @@ int sac_relayout(rlc_handle* h, int blocked) {
     if (h->sac.d.blocked == blocked) return 0;
     if (rlc_h_use_device(h)) return 1;
     const RlcSacDims od = h->sac.d;
-    const RlcSacDims nd = rlc_sac_make_dims(od.S, od.A, od.L1A, od.L2A, od.L1C, od.L2C, od.B, blocked, od.qcat);
+    const RlcSacDims nd = rlc_sac_make_dims(od.S, od.A, od.L1A, od.L2A, od.L1C, od.L2C, od.B, blocked, od.qcat, od.norm);
     const size_t NA = h->sac.n_agents, PP = od.Ppad;
     std::vector<float> dev(NA * PP), compact(od.P), out(NA * PP);
     for (int which = 0; which < 4; which++) {
@@ -96,17 +96,23 @@ int rlc_sac_create(const rlc_sac_config* cfg, rlc_handle** out) {
     RLC_REQUIRE(cfg->actor_l1_dim >= 1 && cfg->actor_l2_dim >= 1 && cfg->critic_l1_dim >= 1 && cfg->critic_l2_dim >= 1,
                 "layer widths must be >= 1");
     RLC_REQUIRE(cfg->pi_lr && cfg->qf_vf_lr && cfg->entropy_scale, "null per-agent array");
+    RLC_REQUIRE(cfg->norm_type == RLC_NORM_NONE || cfg->norm_type == RLC_NORM_LAYER,
+                "norm_type %d: 'batch' (fused batch norm with moving averages, base_network.py:57-59) is not implemented",
+                cfg->norm_type);
+    const int norm = cfg->norm_type == RLC_NORM_LAYER ? 1 : 0;
+    RLC_REQUIRE(!norm || (cfg->actor_l1_dim <= 1024 && cfg->actor_l2_dim <= 1024 && cfg->critic_l1_dim <= 1024 &&
+                          cfg->critic_l2_dim <= 1024), "layer norm: layer widths must be <= 1024");
     rlc_handle* h = new rlc_handle();
     int rc = rlc_h_init_common(h, RLC_ALGO_SAC, cfg->device, cfg->n_agents, cfg->state_dim, cfg->action_dim,
                                cfg->batch_size, cfg->buffer_size, cfg->seed);
     if (rc) { rlc_h_destroy(h); return rc; }
     RlcSacDev& dv = h->sac;
     dv.d = rlc_sac_make_dims(cfg->state_dim, cfg->action_dim, cfg->actor_l1_dim, cfg->actor_l2_dim,
-                             cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size);
+                             cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size, 0, 0, norm);
     // the tile-blocked weight layout goes with the MFMA kernel (the default whenever it supports the shape)
     if (rlc_sac_mfma_supported(dv.d))
         dv.d = rlc_sac_make_dims(cfg->state_dim, cfg->action_dim, cfg->actor_l1_dim, cfg->actor_l2_dim,
-                                 cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size, 1);
+                                 cfg->critic_l1_dim, cfg->critic_l2_dim, cfg->batch_size, 1, 0, norm);
     dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
     dv.clip_state = cfg->clip_state;

@@ -7,7 +7,7 @@
 #pragma once
 #include "rlc_common.h"
 
-#define RLC_SAC_NSEG 20
+#define RLC_SAC_NSEG 32
 
 struct RlcSacDims {
     int S, A, L1A, L2A, L1C, L2C, B;
@@ -15,7 +15,10 @@ struct RlcSacDims {
     int arow0;       // device row of qW2's first action row: L1C (row-major) or the next multiple of 16 (blocked)
     int qcat;        // 0: the action joins Q at layer 2 (sac_network.py:183-196); 1: [state, action] is Q's INPUT
                      // (the ReverseKL / ForwardKL SoftQNetwork, reversekl_network.py:257-276): qW1[S+A,L1c], qW2[L1c,L2c]
+    int norm;        // 1: config.norm_type 'layer' -- tf.contrib.layers.layer_norm before every hidden relu
+                     // (base_network.py:53-56): each hidden layer adds beta then gamma behind its bias
     int pW1, pb1, pW2, pb2, pWm, pbm, pWs, pbs, qW1, qb1, qW2, qb2, qW3, qb3, vW1, vb1, vW2, vb2, vW3, vb3;
+    int pL1b, pL1g, pL2b, pL2g, qL1b, qL1g, qL2b, qL2g, vL1b, vL1g, vL2b, vL2g;      // layer-norm beta / gamma (norm only)
     int Ppi_dev;     // device offset where the qf block starts (pi optimizer owns [0, Ppi_dev))
     int P, Pdev, Ppad, nseg;
     int seg_len[RLC_SAC_NSEG], seg_compact[RLC_SAC_NSEG], seg_dev[RLC_SAC_NSEG];
@@ -24,24 +27,36 @@ struct RlcSacDims {
 };
 
 inline RlcSacDims rlc_sac_make_dims(int S, int A, int L1A, int L2A, int L1C, int L2C, int B, int blocked = 0,
-                                    int qcat = 0) {
+                                    int qcat = 0, int norm = 0) {
     RlcSacDims d;
     d.S = S; d.A = A; d.L1A = L1A; d.L2A = L2A; d.L1C = L1C; d.L2C = L2C; d.B = B;
-    d.blocked = blocked; d.qcat = qcat;
+    d.blocked = blocked; d.qcat = qcat; d.norm = norm;
     d.arow0 = blocked ? ((L1C + 15) & ~15) : L1C;
-    d.nseg = RLC_SAC_NSEG;
-    const int rows[RLC_SAC_NSEG] = {S, 1, L1A, 1, L2A, 1, L2A, 1, qcat ? S + A : S, 1, qcat ? L1C : L1C + A, 1, L2C, 1,
-                                    S, 1, L1C, 1, L2C, 1};
-    const int cols[RLC_SAC_NSEG] = {L1A, L1A, L2A, L2A, A, A, A, A, L1C, L1C, L2C, L2C, 1, 1, L1C, L1C, L2C, L2C, 1, 1};
-    for (int i = 0; i < RLC_SAC_NSEG; i++) {
-        d.seg_rows[i] = rows[i]; d.seg_cols[i] = cols[i];
-        d.seg_big[i] = (i == 2 || i == 10 || i == 16) ? 1 : 0;
-        d.seg_h[i] = i == 10 ? L1C : rows[i];
-    }
+    int n = 0;
+    int* slot[RLC_SAC_NSEG];
+    auto seg = [&](int* where, int r, int c, int big, int h) {
+        d.seg_rows[n] = r; d.seg_cols[n] = c; d.seg_big[n] = (char)big; d.seg_h[n] = h;
+        slot[n++] = where;
+    };
+    auto vec = [&](int* where, int c) { seg(where, 1, c, 0, 1); };
+    auto ln = [&](int* wb, int* wg, int c) { if (norm) { vec(wb, c); vec(wg, c); } };
+    // pi
+    seg(&d.pW1, S, L1A, 0, S); vec(&d.pb1, L1A); ln(&d.pL1b, &d.pL1g, L1A);
+    seg(&d.pW2, L1A, L2A, 1, L1A); vec(&d.pb2, L2A); ln(&d.pL2b, &d.pL2g, L2A);
+    seg(&d.pWm, L2A, A, 0, L2A); vec(&d.pbm, A); seg(&d.pWs, L2A, A, 0, L2A); vec(&d.pbs, A);
+    // qf
+    const int q1r = qcat ? S + A : S, q2r = qcat ? L1C : L1C + A;
+    seg(&d.qW1, q1r, L1C, 0, q1r); vec(&d.qb1, L1C); ln(&d.qL1b, &d.qL1g, L1C);
+    seg(&d.qW2, q2r, L2C, 1, L1C); vec(&d.qb2, L2C); ln(&d.qL2b, &d.qL2g, L2C);
+    seg(&d.qW3, L2C, 1, 0, L2C); vec(&d.qb3, 1);
+    // vf
+    seg(&d.vW1, S, L1C, 0, S); vec(&d.vb1, L1C); ln(&d.vL1b, &d.vL1g, L1C);
+    seg(&d.vW2, L1C, L2C, 1, L1C); vec(&d.vb2, L2C); ln(&d.vL2b, &d.vL2g, L2C);
+    seg(&d.vW3, L2C, 1, 0, L2C); vec(&d.vb3, 1);
+    d.nseg = n;
+    d.pL1b = d.pL1g = d.pL2b = d.pL2g = d.qL1b = d.qL1g = d.qL2b = d.qL2g = d.vL1b = d.vL1g = d.vL2b = d.vL2g = 0;
     rlc_layout_segs(d);
-    int* o[RLC_SAC_NSEG] = {&d.pW1, &d.pb1, &d.pW2, &d.pb2, &d.pWm, &d.pbm, &d.pWs, &d.pbs, &d.qW1, &d.qb1,
-                            &d.qW2, &d.qb2, &d.qW3, &d.qb3, &d.vW1, &d.vb1, &d.vW2, &d.vb2, &d.vW3, &d.vb3};
-    for (int i = 0; i < RLC_SAC_NSEG; i++) *o[i] = d.seg_dev[i];
+    for (int i = 0; i < n; i++) *slot[i] = d.seg_dev[i];
     d.Ppi_dev = d.qW1;
     return d;
 }

@@ -89,6 +89,42 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
     float* dq1 = sc;                sc += (size_t)B * L1C;
     float* dv2 = sc;                sc += (size_t)B * L2C;
     float* dv1 = sc;                sc += (size_t)B * L1C;
+    // layer norm (norm_type 'layer'): normalised pre-activations and 1/std of every hidden layer that is differentiated,
+    // one throw-away pair for the target network
+    const int NORM = d.norm;
+    const size_t lnw = NORM ? 1 : 0;
+    float* pn1 = sc;                sc += lnw * B * L1A;
+    float* pn2 = sc;                sc += lnw * B * L2A;
+    float* qn1 = sc;                sc += lnw * B * L1C;
+    float* qn2 = sc;                sc += lnw * B * L2C;
+    float* qn2p = sc;               sc += lnw * B * L2C;
+    float* vn1 = sc;                sc += lnw * B * L1C;
+    float* vn2 = sc;                sc += lnw * B * L2C;
+    float* tn = sc;                 sc += lnw * B * (L1C > L2C ? L1C : L2C);
+    float* rsd = sc;                sc += lnw * 8 * RLC_MAX_BATCH;      // rstd rows: pi1 pi2 q1 q2 q2pi v1 v2 target
+    float* gtmp = sc;               sc += lnw * B * L2C;                // d Q(s,pi) / d (layer-2 linear output)
+    // Y = act(X W + [E We] + b) with layer norm before the relu when NORM (hidden layers only)
+    auto hidden = [&](const float* X, int K, const float* E, int Ke, const float* P, int oW, int ob, int olb, int olg, int N,
+                      float* Y, float* nh, float* rs) {
+        blk_dense(X, K, K, E, Ke, P + oW, P + ob, N, Y, N, B, NORM ? 0 : 1);
+        if (NORM) {
+            __syncthreads();
+            blk_layernorm_relu(Y, N, B, P + olb, P + olg, nh, rs);
+        }
+    };
+    // layer-norm backward of a hidden layer whose masked output gradient is dY (in place -> gradient of the linear
+    // output, with the PRE-step gamma); returns this thread's (gamma, beta) gradient column sums
+    auto ln_bwd = [&](float* dY, const float* nh, const float* rs, int olg, int N, float& gg, float& gb) {
+        if (!NORM) return;
+        __syncthreads();
+        blk_layernorm_param_grads(dY, nh, N, B, gg, gb);
+        __syncthreads();
+        blk_layernorm_bwd_rows(dY, nh, rs, th + olg, N, B);
+        __syncthreads();
+    };
+    auto ln_adam = [&](const AdamCtx& c, int olb, int olg, int N, float gg, float gb) {
+        if (NORM && tid < N) { adam_apply(c, olg + tid, gg); adam_apply(c, olb + tid, gb); }
+    };
     const float EPS = 1e-6f, LOG2PI = 1.8378770664093453f, HALF_RANGE = 0.5f * (2.0f - (-20.0f));
 
     for (int u = 0; u < n_updates; u++) {
@@ -143,9 +179,9 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
         if (tid == 0 && !eps_in) dv.noise_ctr[agent] = nctr + 1;
 
         // ---- forward: pi ----
-        blk_dense(L.xc, S, S, nullptr, 0, th + d.pW1, th + d.pb1, L1A, ph1, L1A, B, 1);
+        hidden(L.xc, S, nullptr, 0, th, d.pW1, d.pb1, d.pL1b, d.pL1g, L1A, ph1, pn1, rsd + 0 * RLC_MAX_BATCH);
         __syncthreads();
-        blk_dense(ph1, L1A, L1A, nullptr, 0, th + d.pW2, th + d.pb2, L2A, ph2, L2A, B, 1);
+        hidden(ph1, L1A, nullptr, 0, th, d.pW2, d.pb2, d.pL2b, d.pL2g, L2A, ph2, pn2, rsd + 1 * RLC_MAX_BATCH);
         __syncthreads();
         blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWm, th + d.pbm, A, L.mu, A, B, 0);
         blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWs, th + d.pbs, A, L.lsp, A, B, 0);
@@ -171,15 +207,33 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
             dv.tap_logp[(size_t)agent * RLC_MAX_BATCH + b] = lp;
         }
         // ---- forward: Q(s,a), Q(s,pi) (raw state), V(s), V'(s') ----
-        blk_dense(L.x, S, S, nullptr, 0, th + d.qW1, th + d.qb1, L1C, qh1, L1C, B, 1);
-        blk_dense(L.xc, S, S, nullptr, 0, th + d.vW1, th + d.vb1, L1C, vh1, L1C, B, 1);
-        blk_dense(L.x2c, S, S, nullptr, 0, tt + d.vW1, tt + d.vb1, L1C, th1, L1C, B, 1);
-        __syncthreads();
-        blk_dense(qh1, L1C, L1C, L.a, A, th + d.qW2, th + d.qb2, L2C, qh2, L2C, B, 1);
-        blk_dense(qh1, L1C, L1C, L.api, A, th + d.qW2, th + d.qb2, L2C, qh2p, L2C, B, 1);
-        blk_dense(vh1, L1C, L1C, nullptr, 0, th + d.vW2, th + d.vb2, L2C, vh2, L2C, B, 1);
-        blk_dense(th1, L1C, L1C, nullptr, 0, tt + d.vW2, tt + d.vb2, L2C, th2, L2C, B, 1);
-        __syncthreads();
+        if (!NORM) {
+            blk_dense(L.x, S, S, nullptr, 0, th + d.qW1, th + d.qb1, L1C, qh1, L1C, B, 1);
+            blk_dense(L.xc, S, S, nullptr, 0, th + d.vW1, th + d.vb1, L1C, vh1, L1C, B, 1);
+            blk_dense(L.x2c, S, S, nullptr, 0, tt + d.vW1, tt + d.vb1, L1C, th1, L1C, B, 1);
+            __syncthreads();
+            blk_dense(qh1, L1C, L1C, L.a, A, th + d.qW2, th + d.qb2, L2C, qh2, L2C, B, 1);
+            blk_dense(qh1, L1C, L1C, L.api, A, th + d.qW2, th + d.qb2, L2C, qh2p, L2C, B, 1);
+            blk_dense(vh1, L1C, L1C, nullptr, 0, th + d.vW2, th + d.vb2, L2C, vh2, L2C, B, 1);
+            blk_dense(th1, L1C, L1C, nullptr, 0, tt + d.vW2, tt + d.vb2, L2C, th2, L2C, B, 1);
+            __syncthreads();
+        } else {
+            // the layer-norm pass of a layer needs a barrier after its dense pass: one layer at a time
+            hidden(L.x, S, nullptr, 0, th, d.qW1, d.qb1, d.qL1b, d.qL1g, L1C, qh1, qn1, rsd + 2 * RLC_MAX_BATCH);
+            __syncthreads();
+            hidden(L.xc, S, nullptr, 0, th, d.vW1, d.vb1, d.vL1b, d.vL1g, L1C, vh1, vn1, rsd + 5 * RLC_MAX_BATCH);
+            __syncthreads();
+            hidden(L.x2c, S, nullptr, 0, tt, d.vW1, d.vb1, d.vL1b, d.vL1g, L1C, th1, tn, rsd + 7 * RLC_MAX_BATCH);
+            __syncthreads();
+            hidden(qh1, L1C, L.a, A, th, d.qW2, d.qb2, d.qL2b, d.qL2g, L2C, qh2, qn2, rsd + 3 * RLC_MAX_BATCH);
+            __syncthreads();
+            hidden(qh1, L1C, L.api, A, th, d.qW2, d.qb2, d.qL2b, d.qL2g, L2C, qh2p, qn2p, rsd + 4 * RLC_MAX_BATCH);
+            __syncthreads();
+            hidden(vh1, L1C, nullptr, 0, th, d.vW2, d.vb2, d.vL2b, d.vL2g, L2C, vh2, vn2, rsd + 6 * RLC_MAX_BATCH);
+            __syncthreads();
+            hidden(th1, L1C, nullptr, 0, tt, d.vW2, d.vb2, d.vL2b, d.vL2g, L2C, th2, tn, rsd + 7 * RLC_MAX_BATCH);
+            __syncthreads();
+        }
         blk_dense(qh2, L2C, L2C, nullptr, 0, th + d.qW3, th + d.qb3, 1, L.q, 1, B, 0);
         blk_dense(qh2p, L2C, L2C, nullptr, 0, th + d.qW3, th + d.qb3, 1, L.qpi, 1, B, 0);
         blk_dense(vh2, L2C, L2C, nullptr, 0, th + d.vW3, th + d.vb3, 1, L.v, 1, B, 0);
@@ -212,9 +266,19 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
         }
 
         // ---- pi backward seeds: d(alpha*mean(logp) - mean(Q(s,pi))) / d(mu_raw, ls_pre) ----
+        if (NORM) {
+            // d Q(s,pi) / d (layer-2 linear output): the head's weights through the relu mask and the layer norm
+            for (int it = tid; it < B * L2C; it += kThreads) gtmp[it] = qh2p[it] > 0.0f ? th[d.qW3 + it % L2C] : 0.0f;
+            __syncthreads();
+            blk_layernorm_bwd_rows(gtmp, qn2p, rsd + 4 * RLC_MAX_BATCH, th + d.qL2g, L2C, B);
+            __syncthreads();
+        }
         for (int it = tid; it < B * A; it += kThreads) {
             const int b = it / A, j = it % A;
             float ga = 0.0f;
+            if (NORM) {
+                for (int n = 0; n < L2C; n++) ga += gtmp[(size_t)b * L2C + n] * th[d.qW2 + (size_t)(L1C + j) * L2C + n];
+            } else
             for (int n = 0; n < L2C; n++)
                 if (qh2p[(size_t)b * L2C + n] > 0.0f) ga += th[d.qW3 + n] * th[d.qW2 + (size_t)(L1C + j) * L2C + n];
             const float pt = L.pit[it], om = 1.0f - pt * pt;
@@ -243,11 +307,18 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
         }
         __syncthreads();
         blk_dense_bwd_input_ex(L.dls, A, th + d.pWs, ph2, L2A, dp2, B, true);
+        float gg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, gb[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // p1 p2 q1 q2 v1 v2
+        ln_bwd(dq2, qn2, rsd + 3 * RLC_MAX_BATCH, d.qL2g, L2C, gg[3], gb[3]);
+        ln_bwd(dv2, vn2, rsd + 6 * RLC_MAX_BATCH, d.vL2g, L2C, gg[5], gb[5]);
+        ln_bwd(dp2, pn2, rsd + 1 * RLC_MAX_BATCH, d.pL2g, L2A, gg[1], gb[1]);
         blk_dense_bwd_input(dq2, L2C, th + d.qW2, qh1, L1C, dq1, B);
         blk_dense_bwd_input(dv2, L2C, th + d.vW2, vh1, L1C, dv1, B);
         __syncthreads();
         blk_dense_bwd_input(dp2, L2A, th + d.pW2, ph1, L1A, dp1, B);
         __syncthreads();
+        ln_bwd(dq1, qn1, rsd + 2 * RLC_MAX_BATCH, d.qL1g, L1C, gg[2], gb[2]);
+        ln_bwd(dv1, vn1, rsd + 5 * RLC_MAX_BATCH, d.vL1g, L1C, gg[4], gb[4]);
+        ln_bwd(dp1, pn1, rsd + 0 * RLC_MAX_BATCH, d.pL1g, L1A, gg[0], gb[0]);
         // ---- gradients + Adam: pi optimizer, then value optimizer (disjoint parameters) ----
         {
             const AdamCtx cp = {th, mm, vv, adam_alpha(dv.pi_lr[agent], pw[0], pw[1]), tapg};
@@ -255,6 +326,8 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
             blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dls, A, B, cp, d.pWs, d.pbs);
             blk_dense_grad_adam(ph1, L1A, L1A, nullptr, 0, dp2, L2A, B, cp, d.pW2, d.pb2);
             blk_dense_grad_adam(L.xc, S, S, nullptr, 0, dp1, L1A, B, cp, d.pW1, d.pb1);
+            ln_adam(cp, d.pL1b, d.pL1g, L1A, gg[0], gb[0]);
+            ln_adam(cp, d.pL2b, d.pL2g, L2A, gg[1], gb[1]);
             const AdamCtx cq = {th, mm, vv, adam_alpha(dv.qv_lr[agent], pw[2], pw[3]), tapg};
             blk_dense_grad_adam(qh2, L2C, L2C, nullptr, 0, L.dout, 1, B, cq, d.qW3, d.qb3);
             blk_dense_grad_adam(qh1, L1C, L1C, L.a, A, dq2, L2C, B, cq, d.qW2, d.qb2);
@@ -262,6 +335,10 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
             blk_dense_grad_adam(vh2, L2C, L2C, nullptr, 0, L.vt, 1, B, cq, d.vW3, d.vb3);
             blk_dense_grad_adam(vh1, L1C, L1C, nullptr, 0, dv2, L2C, B, cq, d.vW2, d.vb2);
             blk_dense_grad_adam(L.xc, S, S, nullptr, 0, dv1, L1C, B, cq, d.vW1, d.vb1);
+            ln_adam(cq, d.qL1b, d.qL1g, L1C, gg[2], gb[2]);
+            ln_adam(cq, d.qL2b, d.qL2g, L2C, gg[3], gb[3]);
+            ln_adam(cq, d.vL1b, d.vL1g, L1C, gg[4], gb[4]);
+            ln_adam(cq, d.vL2b, d.vL2g, L2C, gg[5], gb[5]);
         }
         __syncthreads();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; pw[2] *= 0.9f; pw[3] *= 0.999f; }
@@ -333,7 +410,9 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_eval_kernel(RlcSacDev dv, Rl
 
 size_t rlc_sac_scratch_floats(const RlcSacDims& d) {
     const size_t B = d.B;
-    return B * ((size_t)2 * d.L1A + 2 * d.L2A + 5 * d.L1C + 6 * d.L2C);
+    const size_t ln = d.norm ? B * ((size_t)d.L1A + d.L2A + 2 * d.L1C + 4 * d.L2C + (d.L1C > d.L2C ? d.L1C : d.L2C)) + 8 * RLC_MAX_BATCH
+                             : 0;
+    return B * ((size_t)2 * d.L1A + 2 * d.L2A + 5 * d.L1C + 6 * d.L2C) + ln;
 }
 
 int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source,

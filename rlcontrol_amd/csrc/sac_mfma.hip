@@ -25,6 +25,7 @@ bool rlc_sac_mfma_supported(const RlcSacDims& d) {
     auto okdim = [](int h) { return h >= 16 && h <= 256 && (h % 4) == 0; };
     if (!(okdim(d.L1A) && okdim(d.L2A) && okdim(d.L1C) && okdim(d.L2C))) return false;
     if (d.qcat) return false;   // the KL agents' input-concatenated Q network is not an SAC shape
+    if (d.norm) return false;   // layer norm: the any-shape kernel (sac_generic.hip)
     if (d.S < 1 || d.S > SMAX) return false;
     if (d.A != 1 && d.A != 2) return false;
     if (d.B < 1 || d.B > 128) return false;

@@ -12,11 +12,11 @@ __device__ __forceinline__ float rlc_clip_scalar(float v, int on, float lo, floa
     return on ? fminf(fmaxf(v, lo), hi) : v;
 }
 
-// LDS floats: x | h1 | h2 | out | eps
+// LDS floats: x | h1 | h2 | out | eps (+ 4: a flag word of the train step) | red (layer-norm row reductions)
 __host__ __device__ inline size_t sac_policy_lds_floats(const RlcSacDims& d) {
-    return (size_t)((d.S + 3) & ~3) + ((d.L1A + 3) & ~3) + ((d.L2A + 3) & ~3) + 2 * ((d.A + 3) & ~3);
+    return (size_t)((d.S + 3) & ~3) + ((d.L1A + 3) & ~3) + ((d.L2A + 3) & ~3) + 2 * ((d.A + 3) & ~3) + 4 + 40;
 }
-struct SacPolicyLds { float *x, *h1, *h2, *out, *eps; };
+struct SacPolicyLds { float *x, *h1, *h2, *out, *eps, *red; };
 __device__ inline SacPolicyLds sac_policy_carve(const RlcSacDims& d, float* base) {
     SacPolicyLds L;
     L.x = base;
@@ -24,6 +24,7 @@ __device__ inline SacPolicyLds sac_policy_carve(const RlcSacDims& d, float* base
     L.h2 = L.h1 + ((d.L1A + 3) & ~3);
     L.out = L.h2 + ((d.L2A + 3) & ~3);
     L.eps = L.out + ((d.A + 3) & ~3);
+    L.red = L.eps + ((d.A + 3) & ~3) + 4;
     return L;
 }
 
@@ -46,19 +47,23 @@ __device__ inline void sac_policy_forward(const RlcSacDims& d, const float* th, 
     for (int k = tid; k < L1A; k += nthr) {
         float acc = 0.0f;
         for (int i = 0; i < S; i++) acc += L.x[i] * th[d.pW1 + i * L1A + k];
-        L.h1[k] = fmaxf(acc + th[d.pb1 + k], 0.0f);
+        acc += th[d.pb1 + k];
+        L.h1[k] = d.norm ? acc : fmaxf(acc, 0.0f);
     }
     __syncthreads();
+    if (d.norm) rlc_row_layernorm_relu(L.h1, L1A, th + d.pL1b, th + d.pL1g, L.red);
     if (d.blocked) {
-        rlc_hidden_forward_row(th + d.pW2, 1, th + d.pb2, L.h1, L1A, L2A, L.h2);
+        rlc_hidden_forward_row(th + d.pW2, 1, th + d.pb2, L.h1, L1A, L2A, L.h2, !d.norm);
     } else {
         for (int n = tid; n < L2A; n += nthr) {
             float acc = 0.0f;
             for (int k = 0; k < L1A; k++) acc += L.h1[k] * th[d.pW2 + (size_t)k * L2A + n];
-            L.h2[n] = fmaxf(acc + th[d.pb2 + n], 0.0f);
+            acc += th[d.pb2 + n];
+            L.h2[n] = d.norm ? acc : fmaxf(acc, 0.0f);
         }
     }
     __syncthreads();
+    if (d.norm) rlc_row_layernorm_relu(L.h2, L2A, th + d.pL2b, th + d.pL2g, L.red);
     const int wave = tid / 64, lane = tid % 64;
     for (int j = wave; j < A; j += nthr / 64) {
         float am = 0.0f, as = 0.0f;

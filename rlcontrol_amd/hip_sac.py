@@ -9,30 +9,47 @@ from ._lib import check, dptr, f64, fptr, iptr
 from .hip_pop import Population
 
 
-def param_layout(S, A, L1A, L2A, L1C, L2C):
-    """name -> (offset, shape), variable creation order under 'main' (sac_network.py:152-172)."""
+NORM_TYPES = {"none": 0, "input_norm": 0, "layer": 1}
+
+
+def param_layout(S, A, L1A, L2A, L1C, L2C, norm_type="input_norm"):
+    """name -> (offset, shape), variable creation order under 'main' (sac_network.py:152-172); with norm_type 'layer'
+    every hidden layer is followed by its layer-norm beta and gamma (tf.contrib.layers.layer_norm creates beta first)."""
+    if norm_type not in NORM_TYPES:
+        raise ValueError("norm_type %r is not implemented (implemented: %s)" % (norm_type, ", ".join(sorted(NORM_TYPES))))
+    ln = NORM_TYPES[norm_type] == 1
+    spec = []
+    for pre, w1, w2, l1, l2 in (("p", (S, L1A), (L1A, L2A), L1A, L2A), ("q", (S, L1C), (L1C + A, L2C), L1C, L2C),
+                                ("v", (S, L1C), (L1C, L2C), L1C, L2C)):
+        spec += [(pre + "W1", w1), (pre + "b1", (l1,))]
+        if ln:
+            spec += [(pre + "L1b", (l1,)), (pre + "L1g", (l1,))]
+        spec += [(pre + "W2", w2), (pre + "b2", (l2,))]
+        if ln:
+            spec += [(pre + "L2b", (l2,)), (pre + "L2g", (l2,))]
+        if pre == "p":
+            spec += [("pWm", (L2A, A)), ("pbm", (A,)), ("pWs", (L2A, A)), ("pbs", (A,))]
+        else:
+            spec += [(pre + "W3", (l2, 1)), (pre + "b3", (1,))]
     out, p = OrderedDict(), 0
-    for name, shp in (("pW1", (S, L1A)), ("pb1", (L1A,)), ("pW2", (L1A, L2A)), ("pb2", (L2A,)),
-                      ("pWm", (L2A, A)), ("pbm", (A,)), ("pWs", (L2A, A)), ("pbs", (A,)),
-                      ("qW1", (S, L1C)), ("qb1", (L1C,)), ("qW2", (L1C + A, L2C)), ("qb2", (L2C,)),
-                      ("qW3", (L2C, 1)), ("qb3", (1,)),
-                      ("vW1", (S, L1C)), ("vb1", (L1C,)), ("vW2", (L1C, L2C)), ("vb2", (L2C,)),
-                      ("vW3", (L2C, 1)), ("vb3", (1,))):
+    for name, shp in spec:
         out[name] = (p, shp)
         p += int(np.prod(shp))
     return out, p
 
 
-def init_params(S, A, L1A, L2A, L1C, L2C, seed):
+def init_params(S, A, L1A, L2A, L1C, L2C, seed, norm_type="input_norm"):
     """Initialiser families of sac_network.py: hidden layers and the mu head U(+-sqrt(3/fan_in)) (:178-270),
     log_std head W ~ U(0,1), b ~ U(+-3e-3) (:273-280), Q / V output layers U(+-3e-3) (:198-201,227-230);
     numpy RandomState(seed) instead of TF's unreproducible stream (distribution parity only)."""
     rng = np.random.RandomState(seed)
-    lay, P = param_layout(S, A, L1A, L2A, L1C, L2C)
+    lay, P = param_layout(S, A, L1A, L2A, L1C, L2C, norm_type)
     th = np.zeros(P, np.float32)
     for name, (off, shp) in lay.items():
         n = int(np.prod(shp))
-        if name == "pWs":
+        if name[1] == "L":                 # layer norm: beta zeros, gamma ones (tf.contrib.layers.layer_norm defaults)
+            th[off:off + n] = 1.0 if name.endswith("g") else 0.0
+        elif name == "pWs":
             th[off:off + n] = rng.uniform(0.0, 1.0, n)
         elif name in ("pbs", "qW3", "qb3", "vW3", "vb3"):
             th[off:off + n] = rng.uniform(-3e-3, 3e-3, n)
@@ -48,10 +65,11 @@ class SACPopulation(Population):
 
     def __init__(self, n_agents, state_dim, action_dim, actor_l1_dim, actor_l2_dim, critic_l1_dim, critic_l2_dim,
                  batch_size, buffer_size, tau, state_min0, state_max0, action_max0, pi_lr, qf_vf_lr, entropy_scale,
-                 seeds, clip_state=True, device=0):
+                 seeds, clip_state=True, device=0, norm_type="input_norm"):
         self._init_base(n_agents, state_dim, action_dim, batch_size)
         self.dims = (self.S, self.A, int(actor_l1_dim), int(actor_l2_dim), int(critic_l1_dim), int(critic_l2_dim))
-        self.layout, self.P = param_layout(*self.dims)
+        self.norm_type = norm_type
+        self.layout, self.P = param_layout(*self.dims, norm_type=norm_type)
         bc = lambda v: np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32).reshape(-1), (self.n_agents,)))
         self._keep = dict(lp=bc(pi_lr), lq=bc(qf_vf_lr), al=bc(entropy_scale),
                           seed=np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, np.uint64).reshape(-1), (self.n_agents,))))
@@ -62,6 +80,7 @@ class SACPopulation(Population):
         cfg.tau, cfg.state_min0, cfg.state_max0, cfg.action_max0 = float(tau), float(state_min0), float(state_max0), float(action_max0)
         cfg.pi_lr, cfg.qf_vf_lr, cfg.entropy_scale = fptr(self._keep["lp"]), fptr(self._keep["lq"]), fptr(self._keep["al"])
         cfg.seed = self._keep["seed"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+        cfg.norm_type = NORM_TYPES[norm_type]
         check(self._lib.rlc_sac_create(ctypes.byref(cfg), ctypes.byref(self._h)))
 
     def set_blob(self, agent, which, values):

@@ -253,3 +253,113 @@ def test_sac_kernel_switch_repacks_weights_and_optimizer_state(hip_lib):
     for w in ("theta", "theta_target", "adam_m", "adam_v"):
         assert _rel(pa.get_blob(0, w), pb.get_blob(0, w)) < 2e-4, w
     pa.close(); pb.close()
+
+
+# ------------------------------------------------------------------------------------------ norm_type: layer
+LN_CASES = [((3, 1, 128, 128, 128, 128), 32), ((8, 2, 64, 48, 40, 56), 17), ((3, 1, 200, 160, 144, 176), 100)]
+
+
+def _benign_ln(dims, th, norm):
+    from oracle.sac_variants import layout
+    lay, _ = layout(dims, norm)
+    th = th.copy()
+    for name, f in (("pWs", 0.02), ("pWm", 0.3)):
+        off, shp = lay[name]
+        th[off:off + int(np.prod(shp))] *= f
+    if norm:                                        # gammas / betas away from their 1 / 0 initial values
+        rng = np.random.RandomState(77)
+        for name, (off, shp) in lay.items():
+            if name[1] == "L":
+                k = int(np.prod(shp))
+                th[off:off + k] = rng.uniform(0.5, 1.5, k) if name.endswith("g") else rng.uniform(-0.3, 0.3, k)
+    return th
+
+
+@pytest.mark.parametrize("dims,B", CASES[:2])
+def test_sac_variant_oracle_reduces_to_the_c_oracle_without_layer_norm(dims, B):
+    from oracle.sac_variants import SacVariantOracle
+    d = SacDims(*dims)
+    th = _benign(d, init_params(d, 1))
+    o = SACOracle(d, th, 1e-2, 1e-1, 0.5, 0.01, -1.0, 1.0, 2.0)
+    t = SacVariantOracle(dims, th, 1e-2, 1e-1, 0.5, 0.01, -1.0, 1.0, 2.0, norm_type="input_norm")
+    rng = np.random.RandomState(3)
+    s, a, s2, r, g, eps = _batch(rng, B, dims[0], dims[1])
+    to, tt = o.update(s, a, s2, r, g, eps, taps=True), t.update(s, a, s2, r, g, eps, taps=True)
+    for k in ("q", "v", "q_pi"):
+        assert _rel(tt[k], to[k]) < 1e-5, k
+    assert _rel(tt["logp"], to["logp"]) < 2e-4
+    assert _rel(tt["grads"], to["grads"]) < 5e-5
+    assert _rel(t.theta_t.numpy(), o.theta_t) < 1e-5
+
+
+@pytest.mark.parametrize("dims,B", LN_CASES[:2])
+def test_sac_layer_norm_oracle_fp32_agrees_with_its_float64_twin(dims, B):
+    import torch
+    from oracle.sac_variants import SacVariantOracle, init_params as ln_init, layout
+    th = _benign_ln(dims, ln_init(dims, 1, True), True)
+    o32 = SacVariantOracle(dims, th, 1e-2, 1e-1, 0.5, 0.01, -1.0, 1.0, 2.0)
+    o64 = SacVariantOracle(dims, th, 1e-2, 1e-1, 0.5, 0.01, -1.0, 1.0, 2.0, dtype=torch.float64)
+    rng = np.random.RandomState(3)
+    s, a, s2, r, g, eps = _batch(rng, B, dims[0], dims[1])
+    t32, t64 = o32.update(s, a, s2, r, g, eps, taps=True), o64.update(s, a, s2, r, g, eps, taps=True)
+    for k in ("q", "v", "q_pi"):
+        assert _rel(t32[k], t64[k]) < 1e-5, k
+    assert _rel(t32["logp"], t64["logp"]) < 2e-4
+    lay, _ = layout(dims, True)
+    for n, (off, shp) in lay.items():
+        k = int(np.prod(shp))
+        assert _rel(t32["grads"][off:off + k], t64["grads"][off:off + k]) < 1e-4, n
+    # layer norm is in the graph: a layer's output does not change when its pre-activation is shifted by a constant
+    P = o64._views(o64.theta)
+    z = torch.tensor(rng.randn(4, dims[2]))
+    assert torch.allclose(o64._act(P, "p", 1, z), o64._act(P, "p", 1, z + 3.0), atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,B", LN_CASES)
+def test_sac_hip_layer_norm_matches_oracle(hip_lib, dims, B):
+    """norm_type 'layer' on the any-shape kernel: taps, every gradient tensor (the layer-norm gammas / betas included),
+    targets and the acting paths against the torch restatement"""
+    from oracle.sac_variants import SacVariantOracle, init_params as ln_init, layout
+    from rlcontrol_amd.hip_sac import SACPopulation, param_layout
+    th = _benign_ln(dims, ln_init(dims, 1, True), True)
+    S, A, L1A, L2A, L1C, L2C = dims
+    pop = SACPopulation(1, S, A, L1A, L2A, L1C, L2C, B, 2048, 0.01, -1.0, 1.0, 2.0, 1e-2, 1e-1, 0.5, seeds=[5],
+                        norm_type="layer")
+    assert pop.kernel_in_use() == "generic"
+    lay, P = layout(dims, True)
+    play, pP = param_layout(*dims, norm_type="layer")
+    assert pP == P and [(k, v) for k, v in play.items()] == [(k, v) for k, v in lay.items()]
+    pop.enable_grad_taps(True)
+    pop.set_params(0, th)
+    o = SacVariantOracle(dims, th, 1e-2, 1e-1, 0.5, 0.01, -1.0, 1.0, 2.0)
+    rng = np.random.RandomState(3)
+    for it in range(3):
+        s, a, s2, r, g, eps = _batch(rng, B, S, A)
+        pop.update_batch(0, s, a, s2, r, g, eps=eps)
+        t = o.update(s, a, s2, r, g, eps, taps=True)
+        tol = 1e-5 if it == 0 else 2e-4
+        for k in ("q", "v", "q_pi", "logp"):
+            assert _rel(pop.last_tap(0, k), t[k]) < (tol if k != "logp" else 20 * tol), (it, k)
+        assert _rel(pop.last_tap(0, "loss"), t["loss"]) < 20 * tol
+        if it == 0:
+            got = pop.last_tap(0, "grads")
+            for n, (off, shp) in lay.items():
+                k = int(np.prod(shp))
+                assert _rel(got[off:off + k], t["grads"][off:off + k]) < 5e-5, n
+            assert _rel(pop.get_blob(0, "theta_target"), o.theta_t.numpy()) < 1e-5
+            assert np.allclose(pop.get_beta_powers(0), o.pw, rtol=1e-6)
+    st = rng.uniform(-2, 2, (1, S))
+    assert _rel(pop.act(st), o.act(st)) < 1e-4
+    e = rng.randn(1, A)
+    assert _rel(pop.act(st, sample=True, eps=e), o.act(st, eps=e)) < 1e-4
+    with pytest.raises(Exception, match="MFMA"):
+        pop.set_kernel("mfma")
+    pop.close()
+
+
+@pytest.mark.gpu
+def test_sac_batch_norm_is_refused(hip_lib):
+    from rlcontrol_amd.hip_sac import SACPopulation
+    with pytest.raises(ValueError, match="not implemented"):
+        SACPopulation(1, 3, 1, 32, 32, 32, 32, 8, 64, 0.01, -1.0, 1.0, 2.0, 1e-3, 1e-3, 0.1, seeds=[1], norm_type="batch")
