@@ -77,7 +77,9 @@ class SacVariantOracle(object):
 
     def _act(self, P, pre, layer, z):
         if self.norm:
-            z = torch.nn.functional.layer_norm(z, (z.shape[-1],), P[pre + "L%dg" % layer], P[pre + "L%db" % layer], LN_EPS)
+            mean = z.mean(-1, keepdim=True)                   # tf.nn.moments over the features: biased variance
+            var = ((z - mean) ** 2).mean(-1, keepdim=True)
+            z = (z - mean) / torch.sqrt(var + LN_EPS) * P[pre + "L%dg" % layer] + P[pre + "L%db" % layer]
         return torch.relu(z)
 
     def _pi_hidden(self, P, xc):
