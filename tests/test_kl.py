@@ -414,3 +414,40 @@ def test_kl_kernel_switch_repacks_weights_and_optimizer_state(hip_lib):
     assert _rel(pa.get_blob(0, "theta_target")[vo:], pb.get_blob(0, "theta_target")[vo:]) < 2e-4
     assert _rel(pa.get_blob(0, "theta"), o.theta.numpy()) < 2e-4
     pa.close(); pb.close()
+
+
+# ----------------------------------------------------------------------------------------- CPU: host mirror
+def test_product_layout_and_initialiser_families_match_the_oracle():
+    """rlcontrol_amd.hip_kl (product) and oracle/kl_torch.py (checker) restate the blob layout and the initialiser
+    families independently; they must agree (same RandomState stream -> same numbers)."""
+    from rlcontrol_amd import hip_kl
+    for dims in (HEADLINE, (7, 1, 24, 20, 28, 16)):
+        lay_p, P_p = hip_kl.param_layout(*dims)
+        lay_o, P_o = K.KlDims(*dims).layout()
+        assert P_p == P_o and list(lay_p.items()) == list(lay_o.items())
+        assert np.array_equal(hip_kl.init_params(*dims, 3), K.init_params(K.KlDims(*dims), 3))
+    th = hip_kl.init_params(*HEADLINE, 0)
+    lay, _ = hip_kl.param_layout(*HEADLINE)
+    for name, (off, shp) in lay.items():
+        blk = th[off:off + int(np.prod(shp))]
+        lim = 3e-3 if name[2:] in ("m", "s", "3") else 1.0 / math.sqrt({"p": {"1": 3, "2": 200}, "q": {"1": 4, "2": 200},
+                                                                      "v": {"1": 3, "2": 200}}[name[0]][name[2:]])
+        assert np.abs(blk).max() <= lim and (blk.size < 20 or np.abs(blk).max() > 0.5 * lim), name
+
+
+def test_kl_jsons_carry_the_reference_sweep_axes():
+    """jsonfiles/agent/{reverse,forward}_kl.json: 36 and 27 settings, first key varying fastest (utils/main_utils.py)."""
+    import json
+    import os
+    from rlcontrol_amd.utils.main_utils import get_sweep_parameters
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "jsonfiles", "agent")
+    from collections import OrderedDict
+    for fn, agent, n in (("reverse_kl.json", "ReverseKL", 36), ("forward_kl.json", "ForwardKL", 27)):
+        with open(os.path.join(root, fn)) as f:
+            js = json.load(f, object_pairs_hook=OrderedDict)
+        assert js["agent"] == agent
+        p0, total = get_sweep_parameters(js["sweeps"], 0)
+        assert total == n and p0["N_param"] == 64 and p0["optim_type"] == "intg" and p0["q_update_type"] == "non_sac"
+    # the setting the reference's notebook ranks first for ForwardKL (plots.ipynb:90): index 18
+    p18, _ = get_sweep_parameters(js["sweeps"], 18)
+    assert (p18["pi_lr"], p18["qf_vf_lr"], p18["entropy_scale"]) == (1e-3, 1e-2, 0.001)
