@@ -283,14 +283,18 @@ int rlc_kl_get_kernel(const rlc_kl* h, int32_t* variant_in_use);
  * Mirrors what NAF_Network_Manager.__init__ / NAF_Network.__init__ read from Config (agents/NAF.py:11-21,
  * agents/network/naf_network.py:6-18; jsonfiles/agent/naf.json).  Parameter blob, variable creation order
  * (naf_network.py:79-107): W1[S][L1] b1 | Wa2[L1][L2] ba2 | Wa3[L2][A] ba3 | Wv2[L1][L2] bv2 | Wv3[L2] bv3 |
- * for c < A: Wd_c[L1] bd_c | for c < A-1: Wn_c[L1][A-1-c] bn_c.   blob selector: 0 theta, 1 target, 2 Adam m, 3 Adam v. */
+ * for c < A: Wd_c[L1] bd_c | for c < A-1: Wn_c[L1][A-1-c] bn_c.   blob selector: 0 theta, 1 target, 2 Adam m, 3 Adam v.
+ * With norm_type 'layer' b1, ba2 and bv2 are each followed by their layer-norm beta[width] gamma[width]. */
 typedef struct rlc_naf_config {
     int32_t device, n_agents, state_dim, action_dim;   /* action_dim <= 6 */
     int32_t l1_dim, l2_dim;                             /* jsonfiles/agent/naf.json:9-10 */
     int32_t batch_size, clip_state;
     int64_t buffer_size;
     float tau;
-    float reserved0;
+    int32_t norm_type;           /* RLC_NORM_NONE ('none' / 'input_norm': activation only) or RLC_NORM_LAYER ('layer':
+                                  * tf.contrib.layers.layer_norm before the relu of the trunk and of both branches,
+                                  * naf_network.py:83,87,93; each of the three adds beta, gamma behind its bias in the
+                                  * blob; any-shape kernel only).  'batch' is not implemented: create fails. */
     const float* state_min;      /* [state_dim] (naf_network.py:73) */
     const float* state_max;
     const float* action_max;     /* [action_dim] scale of tanh (naf_network.py:89) */

@@ -124,7 +124,8 @@ def _make_population(agent_name, members, arg_params):
                                           c0.critic_l2_dim, m[3].random_seed), init_target=True)
         return pop
     check_norm_type(c0, agent_name + " --device_rollout",
-                    ('input_norm', 'layer') if agent_name == "SoftActorCritic" else ('none', 'input_norm'))
+                    {"SoftActorCritic": ('input_norm', 'layer'), "NAF": ('none', 'input_norm', 'layer')}.get(
+                        agent_name, ('none', 'input_norm')))
     if agent_name == "DDPG":
         from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
         if c0.exploration_policy != 'ou_noise':
@@ -152,10 +153,10 @@ def _make_population(agent_name, members, arg_params):
             n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, l1_dim=c0.l1_dim, l2_dim=c0.l2_dim,
             batch_size=c0.batch_size, buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min,
             state_max=c0.state_max, action_max=c0.action_max, learning_rate=[m[3].learning_rate for m in members],
-            seeds=seeds, clip_state=(c0.norm_type != 'none'), device=device)
+            seeds=seeds, clip_state=(c0.norm_type != 'none'), device=device, norm_type=c0.norm_type)
         for i, m in enumerate(members):
-            pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.l1_dim, c0.l2_dim, m[3].random_seed),
-                           init_target=True)
+            pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.l1_dim, c0.l2_dim, m[3].random_seed,
+                                          c0.norm_type), init_target=True)
         return pop
     from rlcontrol_amd.hip_sac import SACPopulation, init_params
     if c0.exploration_policy != 'none' or c0.sample_for_eval == "True" or c0.norm_type == 'none':

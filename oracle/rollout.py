@@ -240,14 +240,18 @@ class NafRolloutOracle(RolloutOracle):
     the action bounds, evaluation uses the greedy action."""
 
     def __init__(self, dims, theta, lr, tau, state_min, state_max, action_max, noise_scale, seed, batch_size,
-                 buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes):
-        self._naf = (lr,)
+                 buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes,
+                 norm_type="input_norm"):
+        self._naf = (lr, norm_type)
         self.noise_scale = np.float32(noise_scale)
         amax = np.asarray(action_max, np.float32).reshape(-1)
         RolloutOracle.__init__(self, dims, theta, 0.0, 0.0, tau, state_min, state_max, -amax, amax, seed, batch_size,
                                buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes)
 
     def _make_net(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state):
+        if self._naf[1] == "layer":      # torch restatement (oracle/naf_variants.py); .theta is a tensor there
+            from .naf_variants import NafVariantOracle
+            return NafVariantOracle(dims.t, theta, self._naf[0], tau, state_min, state_max, action_max, "layer", clip_state)
         from .naf import NAFOracle
         return NAFOracle(dims, theta, self._naf[0], tau, state_min, state_max, action_max, clip_state)
 

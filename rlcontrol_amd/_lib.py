@@ -97,7 +97,7 @@ class rlc_naf_config(ctypes.Structure):
         ("device", ctypes.c_int32), ("n_agents", ctypes.c_int32), ("state_dim", ctypes.c_int32),
         ("action_dim", ctypes.c_int32), ("l1_dim", ctypes.c_int32), ("l2_dim", ctypes.c_int32),
         ("batch_size", ctypes.c_int32), ("clip_state", ctypes.c_int32), ("buffer_size", ctypes.c_int64),
-        ("tau", ctypes.c_float), ("reserved0", ctypes.c_float),
+        ("tau", ctypes.c_float), ("norm_type", ctypes.c_int32),
         ("state_min", ctypes.POINTER(ctypes.c_float)), ("state_max", ctypes.POINTER(ctypes.c_float)),
         ("action_max", ctypes.POINTER(ctypes.c_float)), ("learning_rate", ctypes.POINTER(ctypes.c_float)),
         ("seed", ctypes.POINTER(ctypes.c_uint64)),

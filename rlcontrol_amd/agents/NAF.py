@@ -16,7 +16,7 @@ from ..hip_naf import NAFPopulation, init_params
 class NAF_Network_Manager(BaseNetwork_Manager):
     def __init__(self, config):
         super(NAF_Network_Manager, self).__init__(config)
-        check_norm_type(config, "NAF", ('none', 'input_norm'))
+        check_norm_type(config, "NAF", ('none', 'input_norm', 'layer'))
         self.rng = np.random.RandomState(config.random_seed)      # NAF_Network.rng (naf_network.py:10)
         self.noise_scale = config.noise_scale
         self.population = NAFPopulation(
@@ -24,8 +24,10 @@ class NAF_Network_Manager(BaseNetwork_Manager):
             l2_dim=config.l2_dim, batch_size=config.batch_size, buffer_size=int(config.buffer_size), tau=config.tau,
             state_min=config.state_min, state_max=config.state_max, action_max=config.action_max,
             learning_rate=config.learning_rate, seeds=[np.uint64(config.random_seed)],
-            clip_state=(config.norm_type != 'none'), device=int(getattr(config, "device", 0)))
-        theta0 = init_params(config.state_dim, config.action_dim, config.l1_dim, config.l2_dim, config.random_seed)
+            clip_state=(config.norm_type != 'none'), device=int(getattr(config, "device", 0)),
+            norm_type=config.norm_type)
+        theta0 = init_params(config.state_dim, config.action_dim, config.l1_dim, config.l2_dim, config.random_seed,
+                             config.norm_type)
         self.population.set_params(0, theta0, init_target=True)
 
     def device_replay(self):

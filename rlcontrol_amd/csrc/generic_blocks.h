@@ -6,7 +6,12 @@
 
 namespace gen {
 
-constexpr int kThreads = 1024;
+// workgroup size of the any-shape kernels; a translation unit may lower it before including this header (each .hip
+// is compiled and linked on its own, so the device code of two units never mixes)
+#ifndef RLC_GEN_THREADS
+#define RLC_GEN_THREADS 1024
+#endif
+constexpr int kThreads = RLC_GEN_THREADS;
 constexpr int kRows = 4;   // batch rows per thread-item in the dense loops
 
 typedef float gf4 __attribute__((ext_vector_type(4)));

@@ -50,15 +50,32 @@ __host__ __device__ inline size_t nlds_carve(const RlcNafDims& d, unsigned char*
     return off;
 }
 
+// layer-norm side outputs of one forward pass (norm_type 'layer'): normalised pre-activations [B, width] and 1/std [B]
+// of the trunk, the action branch and the value branch; all null when the pass is not differentiated
+struct NafLnSave { float *n1, *rs1, *na, *rsa, *nv, *rsv; };
+
+// a fresh, opaque pointer to the kernel-argument segment, typed as the population view its first bytes hold
+__device__ __forceinline__ const RlcNafDev* naf_kernarg_view() {
+    unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    typedef const RlcNafDev __attribute__((address_space(4)))* karg_ptr;
+    return (const RlcNafDev*)(karg_ptr)k;
+}
+
 // trunk + value branch (+ optionally the action and L heads) for B rows
 __device__ inline void naf_forward(const RlcNafDims& d, const float* th, const float* xin, int B, float* h1, float* ha,
                                    float* hv, float* z_out /* [B,A] pre-tanh or null */, float* V,
-                                   float* dpre /* or null */, float* npre) {
+                                   float* dpre /* or null */, float* npre, const NafLnSave& ln) {
     const int S = d.S, A = d.A, L1 = d.L1, L2 = d.L2, NN = d.NN;
-    blk_dense(xin, S, S, nullptr, 0, th + d.W1, th + d.b1, L1, h1, L1, B, 1);
+    const int act = d.norm ? 0 : 1;     // with layer norm the relu follows the normalisation
+    blk_dense(xin, S, S, nullptr, 0, th + d.W1, th + d.b1, L1, h1, L1, B, act);
     __syncthreads();
-    blk_dense(h1, L1, L1, nullptr, 0, th + d.Wv2, th + d.bv2, L2, hv, L2, B, 1);
-    if (z_out) blk_dense(h1, L1, L1, nullptr, 0, th + d.Wa2, th + d.ba2, L2, ha, L2, B, 1);
+    if (d.norm) {
+        blk_layernorm_relu(h1, L1, B, th + d.L1b, th + d.L1g, ln.n1, ln.rs1);
+        __syncthreads();
+    }
+    blk_dense(h1, L1, L1, nullptr, 0, th + d.Wv2, th + d.bv2, L2, hv, L2, B, act);
+    if (z_out) blk_dense(h1, L1, L1, nullptr, 0, th + d.Wa2, th + d.ba2, L2, ha, L2, B, act);
     if (dpre) {
         for (int c = 0; c < A; c++) blk_dense(h1, L1, L1, nullptr, 0, th + d.Wd[c], th + d.bd[c], 1, dpre + c, A, B, 0);
         int off = 0;
@@ -68,16 +85,31 @@ __device__ inline void naf_forward(const RlcNafDims& d, const float* th, const f
         }
     }
     __syncthreads();
+    if (d.norm) {
+        blk_layernorm_relu(hv, L2, B, th + d.Lv2b, th + d.Lv2g, ln.nv, ln.rsv);
+        if (z_out) blk_layernorm_relu(ha, L2, B, th + d.La2b, th + d.La2g, ln.na, ln.rsa);
+        __syncthreads();
+    }
     blk_dense(hv, L2, L2, nullptr, 0, th + d.Wv3, th + d.bv3, 1, V, 1, B, 0);
     if (z_out) blk_dense(ha, L2, L2, nullptr, 0, th + d.Wa3, th + d.ba3, A, z_out, A, B, 0);
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, int first_agent, int n_updates, int source,
+__global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv_arg, int first_agent, int n_updates, int source,
                                                                   const long long* host_idx, int grad_taps,
                                                                   const RlcNafRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const RlcNafDims d = dv.d;
+    // The population view is read through the kernel-argument segment pointer (dv_arg is the first argument: offset 0)
+    // that NAF_PHASE() makes opaque again at the start of every phase, so that the scalar loads of its fields stay
+    // inside the phase that uses them.  Read as a by-value argument, every field is an invariant load that the
+    // compiler hoists to the kernel's entry and keeps in SGPRs for the whole launch (650 SGPR spills into VGPR lanes,
+    // those VGPRs spilled in turn); hipcc 7.2 miscompiled this kernel in that regime (rocgdb: the zero high half of a
+    // 64-bit column index clobbered -> a load 48 GiB off its row).
+    const RlcNafDev* dvp;
+#define NAF_PHASE() (dvp = naf_kernarg_view())
+#define dv (*dvp)
+#define d (dvp->d)
+    NAF_PHASE();
     const int S = d.S, A = d.A, L1 = d.L1, L2 = d.L2, B = d.B, NN = d.NN;
     const int agent = first_agent + blockIdx.x, tid = threadIdx.x;
     NLds L;
@@ -92,6 +124,16 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
     float* dha = sc; sc += (size_t)B * L2;
     float* dhv = sc; sc += (size_t)B * L2;
     float* dh1 = sc; sc += (size_t)B * L1;
+    // layer norm: what the backward pass of the three normalised layers needs (the target pass keeps nothing)
+    const int NORM = d.norm;
+    const size_t lnw = NORM ? 1 : 0;
+    NafLnSave lns, lnone = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    lns.n1 = sc;  sc += lnw * B * L1;
+    lns.na = sc;  sc += lnw * B * L2;
+    lns.nv = sc;  sc += lnw * B * L2;
+    lns.rs1 = sc; sc += lnw * RLC_MAX_BATCH;
+    lns.rsa = sc; sc += lnw * RLC_MAX_BATCH;
+    lns.rsv = sc; sc += lnw * RLC_MAX_BATCH;
     float* tapg = grad_taps ? dv.tap_g + (size_t)agent * d.Ppad : nullptr;
 
     for (int u = 0; u < n_updates; u++) {
@@ -99,6 +141,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
             // on-device experiment loop: one environment step first; update when learn() would run
             if (!rlc_naf_train_step_device(rollout, agent, L.pol)) continue;
         }
+        NAF_PHASE();
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
             const unsigned long long call = dv.rep.sample_ctr[agent];
@@ -109,6 +152,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
             for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + u) * B + b];
         }
         __syncthreads();
+        NAF_PHASE();
         for (int b = tid; b < B; b += kThreads) {
             const float *ps, *pa, *ps2;
             if (source == RLC_SRC_STAGING) {
@@ -128,7 +172,8 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
         }
         __syncthreads();
         // ---- target V'(s') and the float64 TD glue (agents/NAF.py:70) ----
-        naf_forward(d, tt, L.x2, B, h1, ha, hv, nullptr, L.V, nullptr, nullptr);
+        NAF_PHASE();
+        naf_forward(d, tt, L.x2, B, h1, ha, hv, nullptr, L.V, nullptr, nullptr, lnone);
         for (int b = tid; b < B; b += kThreads) {
             const float y = (float)(L.r[b] + L.g[b] * (double)L.V[b]);
             L.y[b] = y;
@@ -136,8 +181,10 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
         }
         __syncthreads();
         // ---- online forward ----
-        naf_forward(d, th, L.x, B, h1, ha, hv, L.mt, L.V, L.dpre, L.npre);
+        NAF_PHASE();
+        naf_forward(d, th, L.x, B, h1, ha, hv, L.mt, L.V, L.dpre, L.npre, lns);
         // ---- per sample: L columns, advantage, Q, and the seeds of every head's gradient ----
+        NAF_PHASE();
         for (int b = tid; b < B; b += kThreads) {
             float diff[RLC_NAF_MAX_A], ddiff[RLC_NAF_MAX_A], tanhv[RLC_NAF_MAX_A];
             for (int j = 0; j < A; j++) {
@@ -176,13 +223,28 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
         }
         __syncthreads();
         // ---- hidden-layer gradients with the pre-step weights ----
+        NAF_PHASE();
         blk_dense_bwd_input_ld(L.dz, A, A, th + d.Wa3, ha, L2, dha, B, false);
         blk_dense_bwd_input_ld(L.dV, 1, 1, th + d.Wv3, hv, L2, dhv, B, false);
         __syncthreads();
+        // layer norm: this thread's (gamma, beta) gradient column sums, then dha / dhv / dh1 become the gradients of
+        // the layers' linear outputs (pre-step gamma)
+        float gga = 0.0f, gba = 0.0f, ggv = 0.0f, gbv = 0.0f, gg1 = 0.0f, gb1 = 0.0f;
+        NAF_PHASE();
+        if (NORM) {
+            blk_layernorm_param_grads(dha, lns.na, L2, B, gga, gba);
+            blk_layernorm_param_grads(dhv, lns.nv, L2, B, ggv, gbv);
+            __syncthreads();
+            blk_layernorm_bwd_rows(dha, lns.na, lns.rsa, th + d.La2g, L2, B);
+            blk_layernorm_bwd_rows(dhv, lns.nv, lns.rsv, th + d.Lv2g, L2, B);
+            __syncthreads();
+        }
+        NAF_PHASE();
         blk_dense_bwd_input_ld(dha, L2, L2, th + d.Wa2, h1, L1, dh1, B, false);
         __syncthreads();
         blk_dense_bwd_input_ld(dhv, L2, L2, th + d.Wv2, h1, L1, dh1, B, true);
         __syncthreads();
+        NAF_PHASE();
         for (int c = 0; c < A; c++) {
             blk_dense_bwd_input_ld(L.dd + c, A, 1, th + d.Wd[c], h1, L1, dh1, B, true);
             __syncthreads();
@@ -195,23 +257,42 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
                 off += A - 1 - c;
             }
         }
+        NAF_PHASE();
+        if (NORM) {
+            blk_layernorm_param_grads(dh1, lns.n1, L1, B, gg1, gb1);
+            __syncthreads();
+            blk_layernorm_bwd_rows(dh1, lns.n1, lns.rs1, th + d.L1g, L1, B);
+            __syncthreads();
+        }
         // ---- gradients + one Adam over every tensor ----
+        NAF_PHASE();
         {
             const AdamCtx c = {th, dv.m + (size_t)agent * d.Ppad, dv.v + (size_t)agent * d.Ppad,
                                adam_alpha(dv.lr[agent], pw[0], pw[1]), tapg};
             blk_dense_grad_adam_ld(ha, L2, L2, L.dz, A, A, B, c, d.Wa3, d.ba3);
             blk_dense_grad_adam_ld(hv, L2, L2, L.dV, 1, 1, B, c, d.Wv3, d.bv3);
+            NAF_PHASE();
             blk_dense_grad_adam_ld(h1, L1, L1, dha, L2, L2, B, c, d.Wa2, d.ba2);
             blk_dense_grad_adam_ld(h1, L1, L1, dhv, L2, L2, B, c, d.Wv2, d.bv2);
+            NAF_PHASE();
             for (int cc = 0; cc < A; cc++) blk_dense_grad_adam_ld(h1, L1, L1, L.dd + cc, A, 1, B, c, d.Wd[cc], d.bd[cc]);
             int off = 0;
             for (int cc = 0; cc < A - 1; cc++) {
                 blk_dense_grad_adam_ld(h1, L1, L1, L.dn + off, NN, A - 1 - cc, B, c, d.Wn[cc], d.bn[cc]);
                 off += A - 1 - cc;
             }
+            NAF_PHASE();
             blk_dense_grad_adam_ld(L.x, S, S, dh1, L1, L1, B, c, d.W1, d.b1);
+            if (NORM) {
+                if (tid < L2) {
+                    adam_apply(c, d.La2g + tid, gga); adam_apply(c, d.La2b + tid, gba);
+                    adam_apply(c, d.Lv2g + tid, ggv); adam_apply(c, d.Lv2b + tid, gbv);
+                }
+                if (tid < L1) { adam_apply(c, d.L1g + tid, gg1); adam_apply(c, d.L1b + tid, gb1); }
+            }
         }
         __syncthreads();
+        NAF_PHASE();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
         for (int p = tid; p < d.Pdev; p += kThreads) {
             const float t = tt[p];
@@ -219,13 +300,16 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv, 
         }
         __syncthreads();
     }
+#undef NAF_PHASE
+#undef dv
+#undef d
 }
 
 // greedy action + L columns for one state per agent (predict_action / sample_action's fetch, naf_network.py:144-158)
 __global__ __launch_bounds__(kThreads) void rlc_naf_act_kernel(RlcNafDev dv, int first_agent, const float* states,
                                                                float* mu_out, float* lcols_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const RlcNafDims d = dv.d;
+    const RlcNafDims& d = dv.d;
     const int S = d.S, A = d.A, NL = A * (A + 1) / 2;
     const int agent = first_agent + blockIdx.x, tid = threadIdx.x;
     const NafPolicyLds L = naf_policy_carve(d, (float*)smem);
@@ -247,7 +331,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_eval_kernel(RlcNafDev dv, Rl
     __shared__ double sim[RLC_ENV_STATE];
     __shared__ double obs[8];
     __shared__ int s_done;
-    const RlcNafDims d = dv.d;
+    const RlcNafDims& d = dv.d;
     const int S = d.S;
     const int agent = blockIdx.x / env.eval_episodes, ep = blockIdx.x % env.eval_episodes;
     const int tid = threadIdx.x;
@@ -282,7 +366,10 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_eval_kernel(RlcNafDev dv, Rl
 
 }  // namespace
 
-size_t rlc_naf_scratch_floats(const RlcNafDims& d) { return (size_t)d.B * (2 * (size_t)d.L1 + 4 * (size_t)d.L2); }
+size_t rlc_naf_scratch_floats(const RlcNafDims& d) {
+    const size_t act = (size_t)d.B * (2 * (size_t)d.L1 + 4 * (size_t)d.L2);
+    return d.norm ? act + (size_t)d.B * ((size_t)d.L1 + 2 * (size_t)d.L2) + 3 * RLC_MAX_BATCH : act;
+}
 
 int rlc_launch_naf_update(const RlcNafDev& dv, int first_agent, int n_agents, int n_updates, int source,
                           const long long* idx_dev, int grad_taps, hipStream_t st, const RlcNafRollout* rollout) {

@@ -20,6 +20,7 @@ static inline int naf_ntw_for(const RlcNafDims& d) { return (d.L1 <= 128 && d.L2
 
 bool rlc_naf_mfma_supported(const RlcNafDims& d) {
     auto okdim = [](int h) { return h >= 16 && h <= 256 && (h % 4) == 0; };
+    if (d.norm) return false;       // layer norm: any-shape kernel only
     if (!(okdim(d.L1) && okdim(d.L2))) return false;
     if (d.S < 1 || d.S > SMAX) return false;
     if (d.A != 1 && d.A != 2) return false;

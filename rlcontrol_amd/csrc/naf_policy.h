@@ -38,11 +38,16 @@ __device__ inline NafPolicyLds naf_policy_carve(const RlcNafDims& d, float* base
 __device__ inline void naf_policy_forward(const RlcNafDims& d, const float* th, const NafPolicyLds& L, const float* amax) {
     using namespace gen;
     const int S = d.S, A = d.A, L1 = d.L1, L2 = d.L2, NN = d.NN;
+    const int act = d.norm ? 0 : 1;     // norm_type 'layer': relu after the normalisation (never with the blocked layout)
     __syncthreads();
-    blk_dense(L.x, S, S, nullptr, 0, th + d.W1, th + d.b1, L1, L.h1, L1, 1, 1);
+    blk_dense(L.x, S, S, nullptr, 0, th + d.W1, th + d.b1, L1, L.h1, L1, 1, act);
     __syncthreads();
+    if (d.norm) {
+        blk_layernorm_relu(L.h1, L1, 1, th + d.L1b, th + d.L1g, nullptr, nullptr);
+        __syncthreads();
+    }
     if (d.blocked) rlc_hidden_forward_row(th + d.Wa2, 1, th + d.ba2, L.h1, L1, L2, L.ha);
-    else blk_dense(L.h1, L1, L1, nullptr, 0, th + d.Wa2, th + d.ba2, L2, L.ha, L2, 1, 1);
+    else blk_dense(L.h1, L1, L1, nullptr, 0, th + d.Wa2, th + d.ba2, L2, L.ha, L2, 1, act);
     for (int c = 0; c < A; c++) blk_dense(L.h1, L1, L1, nullptr, 0, th + d.Wd[c], th + d.bd[c], 1, L.dpre + c, A, 1, 0);
     {
         int off = 0;
@@ -52,6 +57,10 @@ __device__ inline void naf_policy_forward(const RlcNafDims& d, const float* th, 
         }
     }
     __syncthreads();
+    if (d.norm) {
+        blk_layernorm_relu(L.ha, L2, 1, th + d.La2b, th + d.La2g, nullptr, nullptr);
+        __syncthreads();
+    }
     blk_dense(L.ha, L2, L2, nullptr, 0, th + d.Wa3, th + d.ba3, A, L.z, A, 1, 0);
     __syncthreads();
     if ((int)threadIdx.x < A) L.out[threadIdx.x] = tanhf(L.z[threadIdx.x]) * amax[threadIdx.x];

@@ -33,7 +33,7 @@ int naf_relayout(rlc_handle* h, int blocked) {
     if (h->naf.d.blocked == blocked) return 0;
     if (rlc_h_use_device(h)) return 1;
     const RlcNafDims od = h->naf.d;
-    const RlcNafDims nd = rlc_naf_make_dims(od.S, od.A, od.L1, od.L2, od.B, blocked);
+    const RlcNafDims nd = rlc_naf_make_dims(od.S, od.A, od.L1, od.L2, od.B, blocked, od.norm);
     const size_t NA = h->naf.n_agents, PP = od.Ppad;
     std::vector<float> dev(NA * PP), compact(od.P), out(NA * PP);
     for (int which = 0; which < 4; which++) {
@@ -70,15 +70,20 @@ int rlc_naf_create(const rlc_naf_config* cfg, rlc_handle** out) {
     RLC_REQUIRE(cfg->l1_dim >= 1 && cfg->l2_dim >= 1, "layer widths must be >= 1");
     RLC_REQUIRE(cfg->action_dim <= RLC_NAF_MAX_A, "NAF supports action_dim <= %d (got %d)", RLC_NAF_MAX_A, cfg->action_dim);
     RLC_REQUIRE(cfg->state_min && cfg->state_max && cfg->action_max && cfg->learning_rate, "null array");
+    RLC_REQUIRE(cfg->norm_type == RLC_NORM_NONE || cfg->norm_type == RLC_NORM_LAYER,
+                "norm_type %d: 'batch' (fused batch norm with moving averages, base_network.py:57-59) is not implemented",
+                cfg->norm_type);
+    const int norm = cfg->norm_type == RLC_NORM_LAYER ? 1 : 0;
+    RLC_REQUIRE(!norm || (cfg->l1_dim <= 1024 && cfg->l2_dim <= 1024), "layer norm: layer widths must be <= 1024");
     rlc_handle* h = new rlc_handle();
     int rc = rlc_h_init_common(h, RLC_ALGO_NAF, cfg->device, cfg->n_agents, cfg->state_dim, cfg->action_dim,
                                cfg->batch_size, cfg->buffer_size, cfg->seed);
     if (rc) { rlc_h_destroy(h); return rc; }
     RlcNafDev& dv = h->naf;
-    dv.d = rlc_naf_make_dims(cfg->state_dim, cfg->action_dim, cfg->l1_dim, cfg->l2_dim, cfg->batch_size);
+    dv.d = rlc_naf_make_dims(cfg->state_dim, cfg->action_dim, cfg->l1_dim, cfg->l2_dim, cfg->batch_size, 0, norm);
     // the tile-blocked weight layout goes with the MFMA kernel (the default whenever it supports the shape)
     if (rlc_naf_mfma_supported(dv.d))
-        dv.d = rlc_naf_make_dims(cfg->state_dim, cfg->action_dim, cfg->l1_dim, cfg->l2_dim, cfg->batch_size, 1);
+        dv.d = rlc_naf_make_dims(cfg->state_dim, cfg->action_dim, cfg->l1_dim, cfg->l2_dim, cfg->batch_size, 1, norm);
     dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
     dv.clip_state = cfg->clip_state;

@@ -9,10 +9,19 @@ from ._lib import check, dptr, f64, fptr, iptr
 from .hip_pop import Population
 
 
-def param_layout(S, A, L1, L2):
-    """name -> (offset, shape), variable creation order of naf_network.py:79-107."""
-    segs = [("W1", (S, L1)), ("b1", (L1,)), ("Wa2", (L1, L2)), ("ba2", (L2,)), ("Wa3", (L2, A)), ("ba3", (A,)),
-            ("Wv2", (L1, L2)), ("bv2", (L2,)), ("Wv3", (L2, 1)), ("bv3", (1,))]
+NORM_TYPES = {"none": 0, "input_norm": 0, "layer": 1}
+
+
+def param_layout(S, A, L1, L2, norm_type="input_norm"):
+    """name -> (offset, shape), variable creation order of naf_network.py:79-107; with norm_type 'layer' the trunk and
+    both branch hidden layers are followed by their layer-norm beta and gamma (tf.contrib.layers.layer_norm creates beta
+    first; base_network.py:53-56, naf_network.py:83,87,93)."""
+    if norm_type not in NORM_TYPES:
+        raise ValueError("norm_type %r is not implemented (implemented: %s)" % (norm_type, ", ".join(sorted(NORM_TYPES))))
+    ln = lambda tag, n: [("L%sb" % tag, (n,)), ("L%sg" % tag, (n,))] if NORM_TYPES[norm_type] == 1 else []
+    segs = [("W1", (S, L1)), ("b1", (L1,))] + ln("1", L1) + [("Wa2", (L1, L2)), ("ba2", (L2,))] + ln("a2", L2) + \
+           [("Wa3", (L2, A)), ("ba3", (A,)), ("Wv2", (L1, L2)), ("bv2", (L2,))] + ln("v2", L2) + \
+           [("Wv3", (L2, 1)), ("bv3", (1,))]
     for c in range(A):
         segs += [("Wd%d" % c, (L1, 1)), ("bd%d" % c, (1,))]
     for c in range(A - 1):
@@ -24,14 +33,19 @@ def param_layout(S, A, L1, L2):
     return out, p
 
 
-def init_params(S, A, L1, L2, seed):
+def init_params(S, A, L1, L2, seed, norm_type="input_norm"):
     """fully_connected defaults (naf_network.py:81-107): Glorot-uniform weights, zero biases; V output weights
-    U(+-3e-3) (:96).  numpy RandomState(seed) stands in for TF's stream (distribution parity only)."""
+    U(+-3e-3) (:96); layer-norm beta zeros, gamma ones.  numpy RandomState(seed) stands in for TF's stream
+    (distribution parity only)."""
     rng = np.random.RandomState(seed)
-    lay, P = param_layout(S, A, L1, L2)
+    lay, P = param_layout(S, A, L1, L2, norm_type)
     th = np.zeros(P, np.float32)
     for name, (off, shp) in lay.items():
         if name.startswith("b"):
+            continue
+        if name.startswith("L"):
+            if name.endswith("g"):
+                th[off:off + shp[0]] = 1.0
             continue
         n = int(np.prod(shp))
         lim = 3e-3 if name == "Wv3" else np.sqrt(6.0 / (shp[0] + shp[1]))
@@ -44,10 +58,11 @@ class NAFPopulation(Population):
     TAP = {"q": 0, "y": 1, "V": 2, "grads": 3}
 
     def __init__(self, n_agents, state_dim, action_dim, l1_dim, l2_dim, batch_size, buffer_size, tau, state_min,
-                 state_max, action_max, learning_rate, seeds, clip_state=True, device=0):
+                 state_max, action_max, learning_rate, seeds, clip_state=True, device=0, norm_type="input_norm"):
         self._init_base(n_agents, state_dim, action_dim, batch_size)
         self.dims = (self.S, self.A, int(l1_dim), int(l2_dim))
-        self.layout, self.P = param_layout(*self.dims)
+        self.norm_type = norm_type
+        self.layout, self.P = param_layout(*self.dims, norm_type=norm_type)
         bc = lambda v, n: np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32).reshape(-1), (n,)))
         self._keep = dict(smin=bc(state_min, self.S), smax=bc(state_max, self.S), amax=bc(action_max, self.A),
                           lr=bc(learning_rate, self.n_agents),
@@ -56,6 +71,7 @@ class NAFPopulation(Population):
         cfg.device, cfg.n_agents, cfg.state_dim, cfg.action_dim = int(device), self.n_agents, self.S, self.A
         cfg.l1_dim, cfg.l2_dim = self.dims[2:]
         cfg.batch_size, cfg.clip_state, cfg.buffer_size, cfg.tau = self.B, 1 if clip_state else 0, int(buffer_size), float(tau)
+        cfg.norm_type = NORM_TYPES[norm_type]
         cfg.state_min, cfg.state_max, cfg.action_max = fptr(self._keep["smin"]), fptr(self._keep["smax"]), fptr(self._keep["amax"])
         cfg.learning_rate = fptr(self._keep["lr"])
         cfg.seed = self._keep["seed"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))

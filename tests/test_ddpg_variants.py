@@ -213,11 +213,18 @@ def test_dropin_agent_accepts_layer_norm_and_rejects_batch_norm(hip_lib):
         assert a.shape == (1,) and abs(a[0]) <= 2.0
     with pytest.raises(ValueError):
         create_agent("DDPG", cfg("batch"))
-    # SoftActorCritic takes 'layer' too (tests/test_sac.py); NAF does not, and says so instead of running as input_norm
-    c = cfg("layer")
-    c.merge_config({"l1_dim": 16, "l2_dim": 16, "noise_scale": 0.3, "learning_rate": 1e-3, "exploration_policy": "none"})
-    with pytest.raises(ValueError):
-        create_agent("NAF", c)
+    # SoftActorCritic and NAF take 'layer' too (tests/test_sac.py, tests/test_naf.py); nobody runs 'batch' as input_norm
+    for norm in ("layer", "batch"):
+        c = cfg(norm)
+        c.merge_config({"l1_dim": 16, "l2_dim": 16, "noise_scale": 0.3, "learning_rate": 1e-3,
+                        "exploration_policy": "none"})
+        if norm == "batch":
+            with pytest.raises(ValueError):
+                create_agent("NAF", c)
+        else:
+            naf = create_agent("NAF", c)
+            naf.reset()
+            assert naf.start(obs, False).shape == (1,) and naf.start(obs, True).shape == (1,)
     c = cfg("batch")
     c.merge_config({"actor_l1_dim": 16, "actor_l2_dim": 16, "critic_l1_dim": 16, "critic_l2_dim": 16, "pi_lr": 1e-3,
                     "qf_vf_lr": 1e-3, "entropy_scale": 0.1, "sample_for_eval": "False", "use_true_q": "False",

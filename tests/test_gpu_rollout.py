@@ -318,6 +318,43 @@ def test_naf_rollout_matches_cpu_restatement(hip_lib, noise):
     pop.close()
 
 
+def test_naf_layer_norm_rollout_matches_cpu_restatement(hip_lib):
+    """norm_type 'layer' in the on-device loop: the training step, the fused update and the evaluation kernel all go
+    through the three layer norms (naf_policy.h, naf_generic.hip) -- against the torch restatement on the same streams"""
+    from oracle.naf import NafDims
+    from oracle.naf_variants import init_params
+    from oracle.rollout import NafRolloutOracle
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    from rlcontrol_amd.hip_naf import NAFPopulation
+    dims, B, seeds, lr, noise = (3, 1, 32, 32), 16, [8, 123456789012], [1e-3, 3e-4], 0.3
+    pop = NAFPopulation(2, *dims, B, 4096, 0.01, SMIN, SMAX, AMAX, lr, seeds=seeds, norm_type="layer")
+    thetas = [init_params(dims, 40 + i, True) for i in range(2)]
+    for i in range(2):
+        pop.set_params(i, thetas[i], init_target=True)
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00009, "EpisodeSteps": 25,
+           "EvalIntervalMilSteps": 0.00004, "EvalEpisodes": 2}
+    exp = DeviceExperiment(pop, env, gamma=0.99, warmup_steps=0, noise_scale=noise)
+    exp.advance(1000)
+    assert exp.total_steps == 90
+    res = exp.results()
+    for a in range(2):
+        orc = NafRolloutOracle(NafDims(*dims), thetas[a], lr[a], 0.01, SMIN, SMAX, AMAX, noise, seeds[a], B, 4096, 0.99, 0,
+                               25, 90, 40, 2, norm_type="layer").run()
+        tr, er, tl, el, ts, _, _, n_started, tc = res[a]
+        assert tl == orc.train_len == [25] * 3 and ts == orc.timesteps_at_eval == [0, 40, 80] and el == orc.eval_len
+        assert pop.replay_size(a) == len(orc.replay) == 87
+        s, act, r, s2, g = pop.replay_gather(a, np.arange(87))
+        os_ = np.array([t[0] for t in orc.replay]); oa = np.array([t[1] for t in orc.replay])
+        pre = B + 1
+        assert np.allclose(s[:pre], os_[:pre], atol=2e-6) and np.allclose(act[:pre], oa[:pre], atol=1e-5)
+        assert np.allclose(s, os_, atol=5e-3) and np.allclose(act, oa, atol=5e-3)
+        assert np.allclose(er[0], orc.eval_ret[0], rtol=1e-5, atol=1e-4)
+        assert np.allclose(er, orc.eval_ret, rtol=5e-3, atol=5e-2)
+        th, want = pop.get_blob(a, "theta"), orc.net.theta.numpy()
+        assert np.max(np.abs(th - want)) < 5e-3 * np.max(np.abs(want))
+    pop.close()
+
+
 @pytest.mark.parametrize("kind,kernel", [("reverse", "mfma"), ("forward", "mfma"), ("reverse", "generic")])
 def test_kl_rollout_matches_cpu_restatement(hip_lib, kind, kernel):
     """The on-device loop for a ReverseKL / ForwardKL population (the SoftActorCritic train step on the KL kernels)

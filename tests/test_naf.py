@@ -215,3 +215,165 @@ def test_naf_kernel_switch_repacks_weights_and_optimizer_state(hip_lib):
     for w in ("theta", "theta_target", "adam_m"):
         assert _rel(pa.get_blob(0, w), pb.get_blob(0, w)) < 2e-4, w
     pa.close(); pb.close()
+
+
+# ------------------------------------------------------------------------------------------ norm_type 'layer'
+LN_CASES = [((3, 1, 64, 48), 17), ((8, 2, 200, 200), 32), ((5, 3, 32, 40), 9)]
+
+
+def _vo(dims, th, norm_type, dtype=None):
+    import torch
+    from oracle.naf_variants import NafVariantOracle
+    smin, smax, amax = _bounds(dims[0], dims[1])
+    return NafVariantOracle(dims, th, 1e-3, 0.01, smin, smax, amax, norm_type=norm_type,
+                            dtype=dtype or torch.float32)
+
+
+@pytest.mark.parametrize("dims,B", LN_CASES)
+def test_naf_variant_oracle_without_norm_is_the_c_oracle(dims, B):
+    """the torch restatement used for layer norm, run with norm_type 'input_norm', must reproduce oracle/naf_oracle.c"""
+    d = NafDims(*dims)
+    th = init_params(d, 2)
+    smin, smax, amax = _bounds(dims[0], dims[1])
+    o = NAFOracle(d, th, 1e-3, 0.01, smin, smax, amax)
+    v = _vo(dims, th, "input_norm")
+    rng = np.random.RandomState(1)
+    for it in range(2):
+        s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+        to, tv = o.update(s, a, s2, r, g, taps=True), v.update(s, a, s2, r, g, taps=True)
+        for k in ("q", "y", "V"):
+            assert _rel(tv[k], to[k]) < (1e-5 if it == 0 else 2e-4), (it, k)
+        if it == 0:
+            lay, _ = d.layout()
+            for n, (off, shp) in lay.items():
+                k = int(np.prod(shp))
+                assert _rel(tv["grads"][off:off + k], to["grads"][off:off + k]) < 3e-5, n
+            assert _rel(v.theta_t.numpy(), o.theta_t) < 1e-5
+    mu, lc = v.act(s[:4])
+    wm, wl = o.act(s[:4])
+    assert _rel(mu, wm) < 1e-5 and _rel(lc, wl) < 1e-5
+
+
+@pytest.mark.parametrize("dims,B", LN_CASES)
+def test_naf_layer_norm_oracle_agrees_with_its_float64_twin(dims, B):
+    import torch
+    from oracle.naf_variants import init_params as vinit, layout
+    th = vinit(dims, 4, True)
+    lay, P = layout(dims, True)
+    assert P == NafDims(*dims).P + 2 * (dims[2] + 2 * dims[3])       # beta + gamma of the trunk and both branches
+    assert list(lay)[:4] == ["W1", "b1", "L1b", "L1g"] and list(lay)[6:8] == ["La2b", "La2g"]
+    rng = np.random.RandomState(3)
+    th = th + (rng.uniform(-0.2, 0.2, P) * np.array([n.startswith("L") for n, (o, s) in lay.items()
+                                                     for _ in range(int(np.prod(s)))])).astype(np.float32)
+    o32, o64 = _vo(dims, th, "layer"), _vo(dims, th, "layer", torch.float64)
+    s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+    t32, t64 = o32.update(s, a, s2, r, g, taps=True), o64.update(s, a, s2, r, g, taps=True)
+    for k in ("q", "y", "V"):
+        assert _rel(t32[k], t64[k]) < 1e-5, k
+    for n, (off, shp) in lay.items():
+        k = int(np.prod(shp))
+        assert _rel(t32["grads"][off:off + k], t64["grads"][off:off + k]) < 1e-4, n
+    for n in ("L1g", "L1b", "La2g", "Lv2g", "Lv2b"):                  # the layer norms are in the gradient path
+        off, shp = lay[n]
+        assert np.max(np.abs(t64["grads"][off:off + shp[0]])) > 0, n
+
+
+def test_naf_host_layout_with_layer_norm_follows_the_oracle():
+    from oracle.naf_variants import layout
+    from rlcontrol_amd.hip_naf import param_layout, init_params as hinit
+    for dims in ((3, 1, 64, 48), (5, 3, 32, 40)):
+        for norm_type in ("input_norm", "layer"):
+            lay, P = layout(dims, norm_type == "layer")
+            got, gotP = param_layout(*dims, norm_type=norm_type)
+            assert gotP == P and [(k, v) for k, v in got.items()] == [(k, v) for k, v in lay.items()]
+        th = hinit(*dims, seed=1, norm_type="layer")
+        lay, _ = layout(dims, True)
+        assert np.all(th[lay["L1g"][0]:lay["L1g"][0] + dims[2]] == 1.0) and np.all(th[lay["L1b"][0]:lay["L1b"][0] + dims[2]] == 0)
+    with pytest.raises(ValueError):
+        param_layout(3, 1, 8, 8, norm_type="batch")
+
+
+def _ln_theta(dims, seed):
+    """initial blob with the layer-norm gammas / betas moved off their 1 / 0 defaults"""
+    from oracle.naf_variants import init_params as vinit, layout
+    lay, P = layout(dims, True)
+    th = vinit(dims, seed, True)
+    rng = np.random.RandomState(seed + 100)
+    for n, (off, shp) in lay.items():
+        if n.startswith("L"):
+            th[off:off + shp[0]] += rng.uniform(-0.2, 0.2, shp[0]).astype(np.float32)
+    return th, lay, P
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,B", LN_CASES + [((8, 1, 128, 96), 100)])
+def test_naf_hip_layer_norm_update_matches_oracle(hip_lib, dims, B):
+    from rlcontrol_amd.hip_naf import NAFPopulation
+    th, lay, P = _ln_theta(dims, 2)
+    smin, smax, amax = _bounds(dims[0], dims[1])
+    pop = NAFPopulation(1, *dims, B, 512, 0.01, smin, smax, amax, 1e-3, seeds=[3], norm_type="layer")
+    assert pop.P == P and pop.kernel_in_use() == "generic"
+    with pytest.raises(RuntimeError):
+        pop.set_kernel("mfma")
+    pop.enable_grad_taps(True)
+    pop.set_params(0, th)
+    assert np.array_equal(pop.get_blob(0, "theta"), th) and np.array_equal(pop.get_blob(0, "theta_target"), th)
+    o = _vo(dims, th, "layer")
+    rng = np.random.RandomState(1)
+    for it in range(3):
+        s, a, s2, r, g = _batch(rng, B, dims[0], dims[1])
+        pop.update_batch(0, s, a, s2, r, g)
+        t = o.update(s, a, s2, r, g, taps=True)
+        tol = 1e-5 if it == 0 else 3e-4
+        for k in ("q", "y", "V"):
+            assert _rel(pop.last_tap(0, k), t[k]) < tol, (it, k)
+        if it == 0:
+            got = pop.last_tap(0, "grads")
+            for n, (off, shp) in lay.items():
+                k = int(np.prod(shp))
+                assert _rel(got[off:off + k], t["grads"][off:off + k]) < 5e-5, n
+            assert _rel(pop.get_blob(0, "theta_target"), o.theta_t.numpy()) < 1e-5
+    st = rng.uniform(-3, 3, (3, dims[0]))
+    for i in range(3):                                               # acting path (B = 1) through the layer norms
+        mu, lc = pop.act(st[i:i + 1], with_lcols=True)
+        wm, wl = o.act(st[i:i + 1])
+        assert _rel(mu, wm) < 3e-4 and _rel(lc, wl) < 3e-4
+    pop.close()
+
+
+@pytest.mark.gpu
+def test_naf_hip_layer_norm_replay_path_and_batch_norm_refused(hip_lib):
+    """fused sample + gather + update on the replay with layer norm, two agents, K updates in one launch"""
+    from rlcontrol_amd.hip_naf import NAFPopulation
+    from rlcontrol_amd import _lib
+    dims, B, N = (8, 2, 64, 64), 32, 600
+    smin, smax, amax = _bounds(8, 2)
+    pop = NAFPopulation(2, *dims, B, N, 0.01, smin, smax, amax, 1e-3, seeds=[3, 4], norm_type="layer")
+    rng = np.random.RandomState(5)
+    data = (rng.uniform(-3, 3, (N, 8)), rng.uniform(-2, 2, (N, 2)), rng.uniform(-16, 0, N), rng.uniform(-3, 3, (N, 8)),
+            np.full(N, 0.99))
+    oracles = []
+    for i in range(2):
+        th, _, _ = _ln_theta(dims, 20 + i)
+        pop.set_params(i, th)
+        pop.replay_add_batch(i, *data)
+        oracles.append(_vo(dims, th, "layer"))
+    idx = np.stack([rng.choice(N, B, replace=False) for _ in range(4)]).reshape(2, 2, B).astype(np.int64)
+    pop.update(2, host_indices=idx)
+    for i in range(2):
+        for k in range(2):
+            j = idx[i, k]
+            t = oracles[i].update(data[0][j], data[1][j], data[3][j], data[2][j], data[4][j], taps=True)
+        for name in ("q", "y", "V"):
+            assert _rel(pop.last_tap(i, name), t[name]) < 3e-4, (i, name)
+    pop.update(3)                                     # device sampler path
+    assert np.all(np.isfinite(pop.get_blob(1, "theta")))
+    pop.close()
+    # the C ABI refuses 'batch' by name (the Python layout helper refuses it before the library is reached)
+    from rlcontrol_amd import hip_naf
+    hip_naf.NORM_TYPES["batch"] = 2
+    try:
+        with pytest.raises(_lib.RlcError, match="batch"):
+            NAFPopulation(1, *dims, B, N, 0.01, smin, smax, amax, 1e-3, seeds=[3], norm_type="batch")
+    finally:
+        del hip_naf.NORM_TYPES["batch"]
