@@ -220,8 +220,10 @@ int rlc_sac_get_kernel(const rlc_sac* h, int32_t* variant_in_use);
  *   pi: W1[S][L1a] b1 W2[L1a][L2a] b2 Wm[L2a][A] bm Ws[L2a][A] bs | q: W1[S+A][L1c] b1 W2[L1c][L2c] b2 W3[L2c] b3 |
  *   v: W1[S][L1c] b1 W2[L1c][L2c] b2 W3[L2c] b3.      blob selector: 0 theta, 1 target (only the v block is live:
  *   target_v_net), 2 Adam exp_avg, 3 Adam exp_avg_sq.
- * action_dim must be 1: the action integral is the Clenshaw-Curtis line rule of the action_dim == 1 branch
- * (reversekl_network.py:64-76); the sparse-grid branch for action_dim > 1 (l_param) is not implemented. */
+ * action_dim 1 .. 6.  The caller supplies the nodes and weights of the action integral: the Clenshaw-Curtis line rule for
+ * one action dimension (reversekl_network.py:64-76), the sparse grid of level l_param above it (:78-108).  Above one
+ * dimension the policy is the reference's MultivariateNormal(mean, diag_embed(std)) -- covariance diag(std), i.e. a
+ * variance of std per component (:383-389) -- reproduced as written; the MFMA kernel covers action_dim 1 only. */
 #define RLC_KL_REVERSE 1
 #define RLC_KL_FORWARD 2
 #define RLC_KL_OPTIM_INTG 0        /* config.optim_type 'intg'      (reverse: soft RKL; forward: the only one implemented there) */
@@ -242,8 +244,9 @@ typedef struct rlc_kl_config {
     int64_t buffer_size;
     float tau;
     float action_max0;               /* action_max[0]: scale of tanh (reversekl_network.py:47) */
-    const float* node_actions;       /* [n_nodes] scheme.points[1:-1] * action_max, fp32 (self.intgrl_actions) */
-    const float* node_weights;       /* [n_nodes] scheme.weights[1:-1], fp32 (self.intgrl_weights) */
+    const float* node_actions;       /* [n_nodes][action_dim] self.intgrl_actions, fp32: scheme.points[1:-1] * action_max for
+                                      * one action dimension (reversekl_network.py:64-72), the sparse grid of :78-108 above it */
+    const float* node_weights;       /* [n_nodes] self.intgrl_weights, fp32 (either sign on the sparse grid) */
     const float* pi_lr;              /* [n_agents] */
     const float* qf_vf_lr;           /* [n_agents] */
     const float* entropy_scale;      /* [n_agents] */

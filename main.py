@@ -90,7 +90,7 @@ _SHARED_KEYS = {
     "NAF": ("l1_dim", "l2_dim", "batch_size", "buffer_size", "tau", "gamma", "warmup_steps", "norm_type",
             "exploration_policy"),
     "ReverseKL": ("actor_l1_dim", "actor_l2_dim", "critic_l1_dim", "critic_l2_dim", "batch_size", "buffer_size", "tau",
-                  "gamma", "warmup_steps", "exploration_policy", "sample_for_eval", "N_param", "optim_type",
+                  "gamma", "warmup_steps", "exploration_policy", "sample_for_eval", "N_param", "l_param", "optim_type",
                   "q_update_type", "use_true_q"),
 }
 _SHARED_KEYS["ForwardKL"] = _SHARED_KEYS["ReverseKL"]
@@ -118,7 +118,8 @@ def _make_population(agent_name, members, arg_params):
             buffer_size=int(c0.buffer_size), tau=c0.tau, action_max0=float(np.asarray(c0.action_max).reshape(-1)[0]),
             pi_lr=[m[3].pi_lr for m in members], qf_vf_lr=[m[3].qf_vf_lr for m in members],
             entropy_scale=[m[3].entropy_scale for m in members], seeds=seeds, n_param=c0.N_param,
-            optim_type=c0.optim_type, q_update_type=c0.q_update_type, device=device)
+            optim_type=c0.optim_type, q_update_type=c0.q_update_type, device=device,
+            l_param=getattr(c0, "l_param", None), action_max=c0.action_max)
         for i, m in enumerate(members):
             pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.actor_l1_dim, c0.actor_l2_dim, c0.critic_l1_dim,
                                           c0.critic_l2_dim, m[3].random_seed), init_target=True)

@@ -10,6 +10,9 @@ Reference lines restated
                    PolicyNetwork with log_std clamped to [-20, 2])
   evaluate         reversekl_network.py:332-357  (z ~ Normal(mean, std) without reparameterisation gradient,
                    log_prob - log(1 - tanh(z)^2 + 1e-6), actions scaled by action_max[0])
+  get_distribution reversekl_network.py:383-389  (action_dim > 1: MultivariateNormal(mean, diag_embed(std)) -- the
+                   covariance is diag(std), so each component has variance std; restated with the same torch class)
+  sparse grid      reversekl_network.py:78-108   (action_dim > 1: Smolyak combination of nested Clenshaw-Curtis rules)
   get_logprob      reversekl_network.py:360-381  (atanh of the normalised node, same squash correction)
   update (reverse) reversekl_network.py:130-218  (optim_type ll / hard_ll / intg / hard_intg; q_update_type sac / non_sac)
   update (forward) forwardkl_network.py:123-207  (optim_type intg: Boltzmann weights exp(Q/alpha - max) / Z)
@@ -52,6 +55,28 @@ def cc_rule(n_points):
     g = g0 / (n ** 2 - 1 + (n % 2))
     w = np.fft.ifft(v2 + g).real
     return pts, np.concatenate([w, w[:1]])
+
+
+def sparse_grid(l_param, action_dim, action_max):
+    """(actions [K, A] fp32, weights [K] fp32) of reversekl_network.py:78-108, on this file's own Clenshaw-Curtis rule."""
+    import itertools
+    from scipy.special import binom
+    l, A = int(l_param), int(action_dim)
+    n_points = [1] + [2 ** i + 1 for i in range(1, l)]
+    rules = [cc_rule(n_points[i]) for i in range(1, l)]
+    points = [np.array([0.])] + [r[0][1:-1] for r in rules]
+    weights = [np.array([2.])] + [r[1][1:-1] for r in rules]
+    acts, wts = [], []
+    for k in itertools.product(range(l), repeat=A):
+        if (np.sum(k) + A < l) or (np.sum(k) + A > l + A - 1):
+            continue
+        coeff = (-1) ** (l + A - np.sum(k) - A + 1) * binom(A - 1, np.sum(k) + A - l)
+        for j in itertools.product(*[range(len(points[ki])) for ki in k]):
+            acts.append(torch.tensor([points[k[i]][j[i]] for i in range(A)], dtype=torch.float32))
+            wts.append(coeff * np.prod([weights[k[i]][j[i]].squeeze() for i in range(A)]))
+    amax = np.broadcast_to(np.asarray(action_max, np.float64).reshape(-1), (A,)).copy()
+    actions = (torch.stack(acts) * torch.tensor(amax)).to(torch.float32)      # float32 * float64 array -> float32 product
+    return actions.numpy(), torch.tensor(wts, dtype=torch.float32).numpy()
 
 
 class KlDims(object):
@@ -115,9 +140,19 @@ def _pi(p, s):
 
 
 def _normal_logprob(value, mean, std):
+    """log_prob of get_distribution(mean, std), with a trailing unit axis: Normal for one action dimension,
+    MultivariateNormal(mean, diag_embed(std)) above it (reversekl_network.py:383-389)"""
+    if mean.shape[-1] > 1:
+        mvn = torch.distributions.MultivariateNormal(mean, torch.diag_embed(std))
+        return mvn.log_prob(value).unsqueeze(-1)
     # torch.distributions.Normal.log_prob
     var = std ** 2
     return -((value - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))
+
+
+def _sample_scale(std):
+    """what multiplies eps in normal.sample(): std for Normal, the Cholesky factor sqrt(std) of the diag(std) covariance"""
+    return std.sqrt() if std.shape[-1] > 1 else std
 
 
 def adam_171(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
@@ -132,11 +167,10 @@ def adam_171(param, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
 
 class KLOracle(object):
     def __init__(self, kind, dims, theta, pi_lr, qv_lr, alpha, tau, amax0, n_param, optim_type="intg",
-                 q_update_type="non_sac"):
+                 q_update_type="non_sac", l_param=None, action_max=None):
         assert kind in KINDS and optim_type in OPTIM_TYPES and q_update_type in Q_UPDATE_TYPES
         if kind == "forward" and optim_type != "intg":
             raise NotImplementedError("ForwardKL implements optim_type 'intg' only (forwardkl_network.py:153-158)")
-        assert dims.t[1] == 1, "the Clenshaw-Curtis line rule is the action_dim == 1 branch"
         self.kind, self.d, self.optim_type, self.q_update_type = kind, dims, optim_type, q_update_type
         self.lay, P = dims.layout()
         self.theta = torch.tensor(np.asarray(theta, np.float32).copy())
@@ -145,10 +179,14 @@ class KLOracle(object):
         self.v = torch.zeros(P)
         self.step = 0
         self.pi_lr, self.qv_lr, self.alpha, self.tau, self.amax0 = float(pi_lr), float(qv_lr), float(alpha), float(tau), float(amax0)
-        x, w = cc_rule(n_param)
-        # torch.tensor(points[1:-1], float32) * action_max (float64) -> float32   (reversekl_network.py:69-71)
-        self.nodes = torch.tensor((x[1:-1].astype(np.float32).astype(np.float64) * self.amax0).astype(np.float32))
-        self.weights = torch.tensor(w[1:-1].astype(np.float32))
+        if dims.t[1] == 1:
+            x, w = cc_rule(n_param)
+            # torch.tensor(points[1:-1], float32) * action_max (float64) -> float32   (reversekl_network.py:69-71)
+            self.nodes = torch.tensor((x[1:-1].astype(np.float32).astype(np.float64) * self.amax0).astype(np.float32)).view(-1, 1)
+            self.weights = torch.tensor(w[1:-1].astype(np.float32))
+        else:
+            na, nw = sparse_grid(l_param, dims.t[1], self.amax0 if action_max is None else action_max)
+            self.nodes, self.weights = torch.tensor(na), torch.tensor(nw)
         self.pi_end = self.lay["qW1"][0]
         self.q_end = self.lay["vW1"][0]
 
@@ -159,7 +197,7 @@ class KLOracle(object):
             p = _views(self.theta, self.lay)
             s = torch.tensor(np.asarray(states, np.float32).reshape(-1, S))
             mean, log_std = _pi(p, s)
-            z = mean if eps is None else mean + log_std.exp() * torch.tensor(np.asarray(eps, np.float32).reshape(mean.shape))
+            z = mean if eps is None else mean + _sample_scale(log_std.exp()) * torch.tensor(np.asarray(eps, np.float32).reshape(mean.shape))
             return (torch.tanh(z) * self.amax0).numpy()
 
     def update(self, s, a, s2, r, gam, eps, taps=False):
@@ -177,7 +215,7 @@ class KLOracle(object):
         v_val = _mlp3(p, "v", s)
         mean, log_std = _pi(p, s)
         std = log_std.exp()
-        z = (mean + std * eps).detach()                       # normal.sample(): no gradient through the draw
+        z = (mean + _sample_scale(std) * eps).detach()        # normal.sample(): no gradient through the draw
         action = torch.tanh(z)
         log_prob = _normal_logprob(z, mean, std) - torch.log(1 - action.pow(2) + 1e-6).sum(-1, keepdim=True)
         new_action = action * self.amax0
@@ -200,7 +238,7 @@ class KLOracle(object):
             intgrl_q = None
         else:
             stacked_s = s.unsqueeze(1).repeat(1, K, 1).reshape(-1, S)
-            tiled_a = self.nodes.view(1, K, 1).repeat(B, 1, 1)
+            tiled_a = self.nodes.view(1, K, A).repeat(B, 1, 1)
             intgrl_q = _mlp3(p, "q", torch.cat([stacked_s, tiled_a.reshape(-1, A)], 1)).reshape(B, K)
             # get_logprob: nodes back through atanh, density of the pre-squash normal, squash correction
             norm_a = tiled_a.permute(1, 0, 2) / self.amax0                             # [K, B, 1]

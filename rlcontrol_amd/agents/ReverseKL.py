@@ -2,6 +2,7 @@
 
 Same construction (``ReverseKL(config)`` from the Config main.py builds out of jsonfiles/agent/reverse_kl.json) and the
 same ``start/step/update/reset`` behaviour: training actions are samples ``tanh(mean + std*eps) * action_max[0]``
+(above one action dimension the reference's MultivariateNormal(mean, diag_embed(std)) makes that ``sqrt(std)*eps``)
 (external exploration raises NotImplementedError as in the reference, :38-39), evaluation uses ``tanh(mean)`` unless
 ``sample_for_eval == "True"``; every update is update_network followed by update_target_network (:83-93).
 The eps stream is ``numpy.RandomState(random_seed)`` on the host (the reference draws it from torch's global
@@ -25,9 +26,6 @@ class KL_Network_Manager(BaseNetwork_Manager):
         self.rng = np.random.RandomState(config.random_seed)
         self.sample_for_eval = config.sample_for_eval == "True"
         self.use_true_q = config.use_true_q == "True"
-        if config.action_dim != 1:
-            raise NotImplementedError("the HIP path implements the action_dim == 1 quadrature of the KL agents "
-                                      "(Clenshaw-Curtis, N_param); the sparse grid for action_dim > 1 (l_param) is not")
         if self.KIND == "forward" and config.optim_type != "intg":
             # forwardkl_network.py:153-158: 'll' raises, any other name leaves policy_loss undefined
             raise NotImplementedError("ForwardKL implements optim_type 'intg' only")
@@ -39,7 +37,8 @@ class KL_Network_Manager(BaseNetwork_Manager):
             action_max0=float(np.asarray(config.action_max).reshape(-1)[0]),
             pi_lr=config.pi_lr, qf_vf_lr=config.qf_vf_lr, entropy_scale=config.entropy_scale,
             seeds=[np.uint64(config.random_seed)], n_param=config.N_param, optim_type=config.optim_type,
-            q_update_type=config.q_update_type, device=int(getattr(config, "device", 0)))
+            q_update_type=config.q_update_type, device=int(getattr(config, "device", 0)),
+            l_param=getattr(config, "l_param", None), action_max=config.action_max)
         theta0 = init_params(config.state_dim, config.action_dim, config.actor_l1_dim, config.actor_l2_dim,
                              config.critic_l1_dim, config.critic_l2_dim, config.random_seed)
         self.population.set_params(0, theta0, init_target=True)

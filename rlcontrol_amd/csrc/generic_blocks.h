@@ -14,6 +14,20 @@ namespace gen {
 constexpr int kThreads = RLC_GEN_THREADS;
 constexpr int kRows = 4;   // batch rows per thread-item in the dense loops
 
+// A fresh, opaque pointer to the kernel-argument segment, typed as the by-value struct T that is the kernel's FIRST
+// argument (offset 0).  Why the update kernels read their population view this way, re-made at the start of every phase:
+// as a by-value argument every field is an invariant load that the compiler hoists to the kernel's entry and holds in
+// SGPRs for the whole launch -- 650 to 900 SGPR spills into VGPR lanes, those VGPRs spilled in turn at the 128-VGPR
+// budget of a 1024-thread workgroup -- and hipcc 7.2 miscompiled naf_generic.hip in that regime.
+// Through an opaque pointer the scalar loads stay inside the phase that uses them.
+template <class T>
+__device__ __forceinline__ const T* kernarg_view() {
+    unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    typedef const T __attribute__((address_space(4)))* karg_ptr;
+    return (const T*)(karg_ptr)k;
+}
+
 typedef float gf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<size_t>(p) & 15) == 0; }
 

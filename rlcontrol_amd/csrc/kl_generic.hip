@@ -8,10 +8,14 @@
 // then Q-Adam, V-Adam, pi-Adam (torch semantics) and the Polyak step of V.
 //   networks      pi: s -> L1a -> L2a -> {mean, log_std clamped to [-20, 2]}; Q: [s, a] -> L1c -> L2c -> 1 (action at the
 //                 INPUT); V, V': s -> L1c -> L2c -> 1                                  (reversekl_network.py:238-330)
-//   sampled z     mean + std * eps, no gradient through the draw (normal.sample()), log pi = N(z) - log(1 - tanh(z)^2 + 1e-6)
-//   action integral (optim_type intg / hard_intg, action_dim 1): Q at the B x K pairs (state_b, node_k) -- the one large
-//                 contraction of the update, [B*K, L1c] x [L1c, L2c] -- and log pi(node_k | state_b) through atanh
-//                 (get_logprob, reversekl_network.py:360-381)
+//   sampled z     mean + std * eps, no gradient through the draw (normal.sample()), log pi = N(z) - sum log(1 - tanh(z)^2 + 1e-6)
+//   action_dim>1  get_distribution builds MultivariateNormal(mean, diag_embed(std)) (reversekl_network.py:383-389): the
+//                 COVARIANCE is diag(std), so component j has variance std_j (not std_j^2): z_j = mean_j + sqrt(std_j) eps_j,
+//                 log N = -sum (z-mean)^2 / (2 std) - sum log sqrt(std) - A log sqrt(2 pi).  Reproduced as written.
+//   action integral (optim_type intg / hard_intg): Q at the B x K pairs (state_b, node_k) -- the one large contraction of
+//                 the update, [B*K, L1c] x [L1c, L2c] -- and log pi(node_k | state_b) through atanh (get_logprob,
+//                 reversekl_network.py:360-381).  The nodes [K, A] and weights [K] come from the host: the Clenshaw-Curtis
+//                 line rule for action_dim 1, the sparse grid of reversekl_network.py:78-108 above it (weights of either sign)
 //     reverse     loss_b = sum_k w_k * -exp(lp) * ((Q_bk - V_b) - alpha * lp)     (hard: without the alpha * lp term)
 //     forward     loss_b = -sum_k w_k * softmax_k(Q_bk / alpha) * lp, softmax normalised with the quadrature weights
 //   ll / hard_ll  loss_b = -lp_b * (Q(s, a_new) - V - alpha * lp_b)                 (hard: without the alpha * lp term)
@@ -25,8 +29,11 @@ namespace {
 
 using namespace gen;
 
+#define RLC_KL_MAX_A 6
+
 struct KLds {
-    float *x, *x2, *a, *eps, *mu, *lsr, *sd, *z, *newa, *lp, *r, *g, *q, *v, *vt, *qn, *dq, *dvs, *dmu, *dls, *red, *adam;
+    // [B, A]: a, eps, mu, lsr (raw log_std head), vr (variance), lsq (log of its square root), z, newa, dmu, dls; [B]: the rest
+    float *x, *x2, *a, *eps, *mu, *lsr, *vr, *lsq, *z, *newa, *lp, *r, *g, *q, *v, *vt, *qn, *dq, *dvs, *dmu, *dls, *red, *adam;
     long long* idx;
     int* pool;
     int* dups;
@@ -40,13 +47,14 @@ __host__ __device__ inline size_t klds_carve(const RlcSacDims& d, unsigned char*
         off += (bytes + 15) & ~(size_t)15;
         return p;
     };
-    const int B = d.B, S = d.S;
+    const int B = d.B, S = d.S, A = d.A;
     KLds L;
     L.idx = (long long*)take(sizeof(long long) * RLC_MAX_BATCH);
     L.x = (float*)take(sizeof(float) * B * S);
     L.x2 = (float*)take(sizeof(float) * B * S);
-    float** pb[] = {&L.a, &L.eps, &L.mu, &L.lsr, &L.sd, &L.z, &L.newa, &L.lp, &L.r, &L.g,
-                    &L.q, &L.v, &L.vt, &L.qn, &L.dq, &L.dvs, &L.dmu, &L.dls};
+    float** pa[] = {&L.a, &L.eps, &L.mu, &L.lsr, &L.vr, &L.lsq, &L.z, &L.newa, &L.dmu, &L.dls};
+    for (auto p : pa) *p = (float*)take(sizeof(float) * B * A);
+    float** pb[] = {&L.lp, &L.r, &L.g, &L.q, &L.v, &L.vt, &L.qn, &L.dq, &L.dvs};
     for (auto p : pb) *p = (float*)take(sizeof(float) * B);
     L.red = (float*)take(sizeof(float) * 16);
     L.adam = (float*)take(sizeof(float) * 4);
@@ -60,13 +68,19 @@ __host__ __device__ inline size_t klds_carve(const RlcSacDims& d, unsigned char*
 // rows of the B x K action integral processed per pass (bounds the scratch when N_param is large)
 __host__ __device__ inline int kl_chunk_rows(int rows) { return rows < 2048 ? rows : 2048; }
 
-__global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, int first_agent, int n_updates,
+__global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv_arg, int first_agent, int n_updates,
                                                                  int source, const long long* host_idx,
                                                                  const float* eps_in, int grad_taps,
                                                                  const RlcSacRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const RlcSacDims d = dv.d;
-    const int S = d.S, L1A = d.L1A, L2A = d.L2A, L1C = d.L1C, L2C = d.L2C, B = d.B, K = dv.kl_nodes;
+    // the population view is read through gen::kernarg_view (generic_blocks.h), made opaque again by KL_PHASE() at the
+    // start of every phase (dv_arg is the first argument: offset 0)
+    const RlcSacDev* dvp;
+#define KL_PHASE() (dvp = kernarg_view<RlcSacDev>())
+#define dv (*dvp)
+#define d (dvp->d)
+    KL_PHASE();
+    const int S = d.S, A = d.A, L1A = d.L1A, L2A = d.L2A, L1C = d.L1C, L2C = d.L2C, B = d.B, K = dv.kl_nodes;
     const int agent = first_agent + blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     KLds L;
@@ -103,6 +117,7 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
             if (!rlc_sac_train_step_device(rollout, agent, L.pol)) continue;
         }
         // ---- sample + gather ----
+        KL_PHASE();
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
             const unsigned long long call = dv.rep.sample_ctr[agent];
@@ -119,25 +134,28 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
             const float *ps, *pa, *ps2;
             if (source == RLC_SRC_STAGING) {
                 const size_t slot = (size_t)agent * RLC_MAX_BATCH + b;
-                ps = dv.rep.gs + slot * S; pa = dv.rep.ga + slot; ps2 = dv.rep.gs2 + slot * S;
+                ps = dv.rep.gs + slot * S; pa = dv.rep.ga + slot * A; ps2 = dv.rep.gs2 + slot * S;
                 L.r[b] = (float)dv.rep.gr[slot]; L.g[b] = (float)dv.rep.gg[slot];
             } else {
                 const size_t slot = (size_t)agent * dv.rep.cap + ring_slot(ring, dv.rep.cap, L.idx[b]);
-                ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot; ps2 = dv.rep.rs2 + slot * S;
+                ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot * A; ps2 = dv.rep.rs2 + slot * S;
                 L.r[b] = (float)dv.rep.rr[slot]; L.g[b] = (float)dv.rep.rg[slot];
             }
             for (int i = 0; i < S; i++) { L.x[b * S + i] = ps[i]; L.x2[b * S + i] = ps2[i]; }
-            L.a[b] = pa[0];
-            float e;
-            if (eps_in) {
-                e = eps_in[((size_t)blockIdx.x * n_updates + u) * B + b];
-            } else {
-                const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ RLC_KEY_SAC_EPS, nctr, (unsigned long long)b >> 1);
-                float n0, n1;
-                philox_normal2(p, n0, n1);
-                e = (b & 1) ? n1 : n0;
+            for (int j = 0; j < A; j++) {
+                const int e_at = b * A + j;
+                L.a[e_at] = pa[j];
+                float e;
+                if (eps_in) {
+                    e = eps_in[((size_t)blockIdx.x * n_updates + u) * B * A + e_at];
+                } else {
+                    const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ RLC_KEY_SAC_EPS, nctr, (unsigned long long)e_at >> 1);
+                    float n0, n1;
+                    philox_normal2(p, n0, n1);
+                    e = (e_at & 1) ? n1 : n0;
+                }
+                L.eps[e_at] = e;
             }
-            L.eps[b] = e;
         }
         if (tid == 0) {
             // torch's Adam: theta -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + 1e-8); with c = sqrt(1 - b2^t)
@@ -151,8 +169,9 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
         if (tid == 0 && !eps_in) dv.noise_ctr[agent] = nctr + 1;
 
         // ---- forward: pi, Q(s,a), V(s), V'(s') ----
+        KL_PHASE();
         blk_dense(L.x, S, S, nullptr, 0, th + d.pW1, th + d.pb1, L1A, ph1, L1A, B, 1);
-        blk_dense(L.x, S, S, L.a, 1, th + d.qW1, th + d.qb1, L1C, qh1, L1C, B, 1);
+        blk_dense(L.x, S, S, L.a, A, th + d.qW1, th + d.qb1, L1C, qh1, L1C, B, 1);
         blk_dense(L.x, S, S, nullptr, 0, th + d.vW1, th + d.vb1, L1C, vh1, L1C, B, 1);
         blk_dense(L.x2, S, S, nullptr, 0, tt + d.vW1, tt + d.vb1, L1C, th1, L1C, B, 1);
         if (integral) blk_dense(L.x, S, S, nullptr, 0, th + d.qW1, th + d.qb1, L1C, z1s, L1C, B, 0);
@@ -162,26 +181,38 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
         blk_dense(vh1, L1C, L1C, nullptr, 0, th + d.vW2, th + d.vb2, L2C, vh2, L2C, B, 1);
         blk_dense(th1, L1C, L1C, nullptr, 0, tt + d.vW2, tt + d.vb2, L2C, th2, L2C, B, 1);
         __syncthreads();
-        blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWm, th + d.pbm, 1, L.mu, 1, B, 0);
-        blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWs, th + d.pbs, 1, L.lsr, 1, B, 0);
+        blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWm, th + d.pbm, A, L.mu, A, B, 0);
+        blk_dense(ph2, L2A, L2A, nullptr, 0, th + d.pWs, th + d.pbs, A, L.lsr, A, B, 0);
         blk_dense(qh2, L2C, L2C, nullptr, 0, th + d.qW3, th + d.qb3, 1, L.q, 1, B, 0);
         blk_dense(vh2, L2C, L2C, nullptr, 0, th + d.vW3, th + d.vb3, 1, L.v, 1, B, 0);
         blk_dense(th2, L2C, L2C, nullptr, 0, tt + d.vW3, tt + d.vb3, 1, L.vt, 1, B, 0);
         __syncthreads();
         // evaluate(): draw, squash, log-density of the draw (reversekl_network.py:332-357)
+        KL_PHASE();
         for (int b = tid; b < B; b += kThreads) {
-            const float ls = fminf(fmaxf(L.lsr[b], -20.0f), 2.0f);
-            const float sd = expf(ls), mu = L.mu[b];
-            const float z = mu + sd * L.eps[b];
-            const float t = tanhf(z);
-            const float dz = z - mu;
-            const float lp = -(dz * dz) / (2.0f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI - logf(1.0f - t * t + EPS);
-            L.sd[b] = sd; L.z[b] = z; L.lp[b] = lp; L.newa[b] = t * amax0;
+            float quad = 0.0f, corr = 0.0f;
+            for (int j = 0; j < A; j++) {
+                const int at = b * A + j;
+                const float ls = fminf(fmaxf(L.lsr[at], -20.0f), 2.0f);
+                const float sd = expf(ls), mu = L.mu[at];
+                // Normal(mean, std) for one action dimension; MultivariateNormal with covariance diag(std) above it
+                const float var = A == 1 ? sd * sd : sd, sq = A == 1 ? sd : sqrtf(sd);
+                const float z = mu + sq * L.eps[at];
+                const float t = tanhf(z);
+                const float dz = z - mu;
+                const float lsq = logf(sq);
+                quad += -(dz * dz) / (2.0f * var) - lsq;
+                corr += logf(1.0f - t * t + EPS);
+                L.vr[at] = var; L.lsq[at] = lsq; L.z[at] = z; L.newa[at] = t * amax0;
+            }
+            const float lp = quad - (float)A * LOG_SQRT_2PI - corr;
+            L.lp[b] = lp;
             dv.tap_logp[(size_t)agent * RLC_MAX_BATCH + b] = lp;
         }
         __syncthreads();
         // Q(s, a_new): the V target of q_update_type 'sac' and the advantage of the ll updates
-        blk_dense(L.x, S, S, L.newa, 1, th + d.qW1, th + d.qb1, L1C, nh1, L1C, B, 1);
+        KL_PHASE();
+        blk_dense(L.x, S, S, L.newa, A, th + d.qW1, th + d.qb1, L1C, nh1, L1C, B, 1);
         __syncthreads();
         blk_dense(nh1, L1C, L1C, nullptr, 0, th + d.qW2, th + d.qb2, L2C, nh2, L2C, B, 1);
         __syncthreads();
@@ -189,6 +220,7 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
         __syncthreads();
 
         // ---- value seeds (MSELoss: mean over the B x 1 outputs) and their losses ----
+        KL_PHASE();
         float ql = 0.0f, vl = 0.0f, pl = 0.0f;
         for (int b = tid; b < B; b += kThreads) {
             const float tq = L.r[b] + L.g[b] * L.vt[b];
@@ -204,23 +236,31 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
             if (!integral) {
                 // -log_prob * (advantage).detach(): the gradient reaches mean / log_std through N(z; mean, std) only
                 const float adv = (L.qn[b] - L.v[b]) - (dv.kl_optim == RLC_KL_OPTIM_LL ? alpha_ent * L.lp[b] : 0.0f);
-                const float coef = -adv * invB, dz = L.z[b] - L.mu[b], var = L.sd[b] * L.sd[b];
-                const bool inside = L.lsr[b] >= -20.0f && L.lsr[b] <= 2.0f;
+                const float coef = -adv * invB;
                 pl += -L.lp[b] * adv;
-                L.dmu[b] = coef * dz / var;
-                L.dls[b] = inside ? coef * (dz * dz / var - 1.0f) : 0.0f;
+                for (int j = 0; j < A; j++) {
+                    const int at = b * A + j;
+                    const float dz = L.z[at] - L.mu[at], var = L.vr[at];
+                    const bool inside = L.lsr[at] >= -20.0f && L.lsr[at] <= 2.0f;
+                    L.dmu[at] = coef * dz / var;
+                    // d log N / d log_std: variance std^2 (one dimension) or std (the diag(std) covariance)
+                    L.dls[at] = !inside ? 0.0f : A == 1 ? coef * (dz * dz / var - 1.0f) : coef * (dz * dz / (2.0f * var) - 0.5f);
+                }
             }
         }
         __syncthreads();
 
         if (integral) {
-            // ---- Q at the quadrature nodes: rows rho = b*K + k, layer 1 = relu(z1s[b] + a_k * W1[action row]) ----
-            const float* w1a = th + d.qW1 + (size_t)S * L1C;
+            // ---- Q at the quadrature nodes: rows rho = b*K + k, layer 1 = relu(z1s[b] + a_k . W1[action rows]) ----
             for (int r0 = 0; r0 < rows; r0 += chunk) {
+                KL_PHASE();
+                const float* w1a = th + d.qW1 + (size_t)S * L1C;
                 const int nr = min(chunk, rows - r0);
                 for (int it = tid; it < nr * L1C; it += kThreads) {
                     const int rho = r0 + it / L1C, n = it % L1C;
-                    ih1[it] = fmaxf(z1s[(size_t)(rho / K) * L1C + n] + dv.kl_node_a[rho % K] * w1a[n], 0.0f);
+                    float acc = z1s[(size_t)(rho / K) * L1C + n];
+                    for (int j = 0; j < A; j++) acc += dv.kl_node_a[(rho % K) * A + j] * w1a[(size_t)j * L1C + n];
+                    ih1[it] = fmaxf(acc, 0.0f);
                 }
                 __syncthreads();
                 blk_dense(ih1, L1C, L1C, nullptr, 0, th + d.qW2, th + d.qb2, L2C, ih2, L2C, nr, 1);
@@ -238,8 +278,9 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
                 __syncthreads();
             }
             // ---- one wave per state: log pi at the nodes, the integrand's derivative, seeds of mean and log_std ----
+            KL_PHASE();
             for (int b = wave; b < B; b += kThreads / 64) {
-                const float mu = L.mu[b], sd = L.sd[b], var = sd * sd, lsd = logf(sd), vb = L.v[b];
+                const float vb = L.v[b];
                 float shift = -INFINITY, zsum = 0.0f;
                 if (dv.kl_kind == RLC_KL_FORWARD) {
                     for (int k = lane; k < K; k += 64) shift = fmaxf(shift, iq[b * K + k] / alpha_ent);
@@ -248,12 +289,23 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
                     zsum = wave_sum64(zsum);
                     zsum = __shfl(zsum, 0, 64);
                 }
-                float gm = 0.0f, gs = 0.0f, loss = 0.0f;
+                float gm[RLC_KL_MAX_A], gs[RLC_KL_MAX_A], loss = 0.0f;
+#pragma unroll
+                for (int j = 0; j < RLC_KL_MAX_A; j++) { gm[j] = 0.0f; gs[j] = 0.0f; }
                 for (int k = lane; k < K; k += 64) {
-                    const float an = dv.kl_node_a[k] / amax0, w = dv.kl_node_w[k];
-                    const float uu = (logf(1.0f + an) - logf(1.0f - an)) / 2.0f;
-                    const float du = uu - mu;
-                    const float lp = -(du * du) / (2.0f * var) - lsd - LOG_SQRT_2PI - logf(1.0f - an * an + EPS);
+                    const float w = dv.kl_node_w[k];
+                    float quad = 0.0f, corr = 0.0f, du[RLC_KL_MAX_A];
+#pragma unroll
+                    for (int j = 0; j < RLC_KL_MAX_A; j++) {
+                        if (j < A) {
+                            const float an = dv.kl_node_a[k * A + j] / amax0;
+                            const float uu = (logf(1.0f + an) - logf(1.0f - an)) / 2.0f;
+                            du[j] = uu - L.mu[b * A + j];
+                            quad += -(du[j] * du[j]) / (2.0f * L.vr[b * A + j]) - L.lsq[b * A + j];
+                            corr += logf(1.0f - an * an + EPS);
+                        }
+                    }
+                    const float lp = quad - (float)A * LOG_SQRT_2PI - corr;
                     float coef;   // d loss_b / d lp_k
                     if (dv.kl_kind == RLC_KL_FORWARD) {
                         const float bp = expf(iq[b * K + k] / alpha_ent - shift) / zsum;
@@ -269,16 +321,28 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
                             coef = -e * adv * w;
                         }
                     }
-                    gm += coef * (du / var);
-                    gs += coef * (du * du / var - 1.0f);
+#pragma unroll
+                    for (int j = 0; j < RLC_KL_MAX_A; j++) {
+                        if (j < A) {
+                            const float var = L.vr[b * A + j];
+                            gm[j] += coef * (du[j] / var);
+                            gs[j] += A == 1 ? coef * (du[j] * du[j] / var - 1.0f) : coef * (du[j] * du[j] / (2.0f * var) - 0.5f);
+                        }
+                    }
                 }
-                gm = wave_sum64(gm); gs = wave_sum64(gs); loss = wave_sum64(loss);
-                if (lane == 0) {
-                    const bool inside = L.lsr[b] >= -20.0f && L.lsr[b] <= 2.0f;
-                    L.dmu[b] = gm * invB;
-                    L.dls[b] = inside ? gs * invB : 0.0f;
-                    L.lp[b] = loss;          // per-state loss; lp itself is already tapped and consumed
+                loss = wave_sum64(loss);
+#pragma unroll
+                for (int j = 0; j < RLC_KL_MAX_A; j++) {
+                    if (j < A) {
+                        const float m = wave_sum64(gm[j]), sg = wave_sum64(gs[j]);
+                        if (lane == 0) {
+                            const bool inside = L.lsr[b * A + j] >= -20.0f && L.lsr[b * A + j] <= 2.0f;
+                            L.dmu[b * A + j] = m * invB;
+                            L.dls[b * A + j] = inside ? sg * invB : 0.0f;
+                        }
+                    }
                 }
+                if (lane == 0) L.lp[b] = loss;          // per-state loss; lp itself is already tapped and consumed
             }
             __syncthreads();
             for (int b = tid; b < B; b += kThreads) pl += L.lp[b];
@@ -291,40 +355,47 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv, i
         }
 
         // ---- hidden-layer gradients, all with the pre-update weights ----
-        blk_dense_bwd_input_ex(L.dmu, 1, th + d.pWm, ph2, L2A, dp2, B, false);
+        KL_PHASE();
+        blk_dense_bwd_input_ex(L.dmu, A, th + d.pWm, ph2, L2A, dp2, B, false);
         for (int it = tid; it < B * L2C; it += kThreads) {
             const int b = it / L2C, n = it % L2C;
             dq2[it] = qh2[it] > 0.0f ? L.dq[b] * th[d.qW3 + n] : 0.0f;
             dv2[it] = vh2[it] > 0.0f ? L.dvs[b] * th[d.vW3 + n] : 0.0f;
         }
         __syncthreads();
-        blk_dense_bwd_input_ex(L.dls, 1, th + d.pWs, ph2, L2A, dp2, B, true);
+        blk_dense_bwd_input_ex(L.dls, A, th + d.pWs, ph2, L2A, dp2, B, true);
         blk_dense_bwd_input(dq2, L2C, th + d.qW2, qh1, L1C, dq1, B);
         blk_dense_bwd_input(dv2, L2C, th + d.vW2, vh1, L1C, dv1, B);
         __syncthreads();
         blk_dense_bwd_input(dp2, L2A, th + d.pW2, ph1, L1A, dp1, B);
         __syncthreads();
         // ---- gradients + Adam: q_optimizer, v_optimizer, pi_optimizer (disjoint parameters) ----
+        KL_PHASE();
         {
             const AdamCtx cq = {th, mm, vv, L.adam[1], tapg, L.adam[2]};
             blk_dense_grad_adam(qh2, L2C, L2C, nullptr, 0, L.dq, 1, B, cq, d.qW3, d.qb3);
             blk_dense_grad_adam(qh1, L1C, L1C, nullptr, 0, dq2, L2C, B, cq, d.qW2, d.qb2);
-            blk_dense_grad_adam(L.x, S, S, L.a, 1, dq1, L1C, B, cq, d.qW1, d.qb1);
+            blk_dense_grad_adam(L.x, S, S, L.a, A, dq1, L1C, B, cq, d.qW1, d.qb1);
             blk_dense_grad_adam(vh2, L2C, L2C, nullptr, 0, L.dvs, 1, B, cq, d.vW3, d.vb3);
             blk_dense_grad_adam(vh1, L1C, L1C, nullptr, 0, dv2, L2C, B, cq, d.vW2, d.vb2);
             blk_dense_grad_adam(L.x, S, S, nullptr, 0, dv1, L1C, B, cq, d.vW1, d.vb1);
+            KL_PHASE();
             const AdamCtx cp = {th, mm, vv, L.adam[0], tapg, L.adam[2]};
-            blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dmu, 1, B, cp, d.pWm, d.pbm);
-            blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dls, 1, B, cp, d.pWs, d.pbs);
+            blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dmu, A, B, cp, d.pWm, d.pbm);
+            blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dls, A, B, cp, d.pWs, d.pbs);
             blk_dense_grad_adam(ph1, L1A, L1A, nullptr, 0, dp2, L2A, B, cp, d.pW2, d.pb2);
             blk_dense_grad_adam(L.x, S, S, nullptr, 0, dp1, L1A, B, cp, d.pW1, d.pb1);
         }
         __syncthreads();
         if (tid == 0) dv.kl_step[agent] = step;
         // ---- update_target_network: the V network only, target*(1-tau) + param*tau ----
+        KL_PHASE();
         for (int p = d.vW1 + tid; p < d.Pdev; p += kThreads) tt[p] = tt[p] * (1.0f - dv.tau) + th[p] * dv.tau;
         __syncthreads();
     }
+#undef KL_PHASE
+#undef dv
+#undef d
 }
 
 // predict_action (tanh(mean) * action_max) / sample_action (tanh(mean + std*eps) * action_max) for one state per
@@ -358,7 +429,8 @@ int rlc_launch_kl_update(const RlcSacDev& dv, int first_agent, int n_agents, int
                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
                          const RlcSacRollout* rollout) {
     const size_t lds = klds_carve(dv.d, nullptr, nullptr);
-    RLC_REQUIRE(dv.d.A == 1 && dv.d.qcat == 1, "the KL update kernel needs action_dim 1 and the input-concatenated Q layout");
+    RLC_REQUIRE(dv.d.A >= 1 && dv.d.A <= RLC_KL_MAX_A && dv.d.qcat == 1,
+                "the KL update kernel needs action_dim in [1,%d] and the input-concatenated Q layout", RLC_KL_MAX_A);
     const bool integral = dv.kl_optim == RLC_KL_OPTIM_INTG || dv.kl_optim == RLC_KL_OPTIM_HARD_INTG;
     RLC_REQUIRE(!integral || dv.kl_nodes >= 1, "no quadrature nodes");
     RLC_REQUIRE(lds <= 64 * 1024, "KL kernel needs %zu B of LDS", lds);

@@ -54,14 +54,6 @@ __host__ __device__ inline size_t nlds_carve(const RlcNafDims& d, unsigned char*
 // of the trunk, the action branch and the value branch; all null when the pass is not differentiated
 struct NafLnSave { float *n1, *rs1, *na, *rsa, *nv, *rsv; };
 
-// a fresh, opaque pointer to the kernel-argument segment, typed as the population view its first bytes hold
-__device__ __forceinline__ const RlcNafDev* naf_kernarg_view() {
-    unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(k));
-    typedef const RlcNafDev __attribute__((address_space(4)))* karg_ptr;
-    return (const RlcNafDev*)(karg_ptr)k;
-}
-
 // trunk + value branch (+ optionally the action and L heads) for B rows
 __device__ inline void naf_forward(const RlcNafDims& d, const float* th, const float* xin, int B, float* h1, float* ha,
                                    float* hv, float* z_out /* [B,A] pre-tanh or null */, float* V,
@@ -99,14 +91,10 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv_a
                                                                   const long long* host_idx, int grad_taps,
                                                                   const RlcNafRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // The population view is read through the kernel-argument segment pointer (dv_arg is the first argument: offset 0)
-    // that NAF_PHASE() makes opaque again at the start of every phase, so that the scalar loads of its fields stay
-    // inside the phase that uses them.  Read as a by-value argument, every field is an invariant load that the
-    // compiler hoists to the kernel's entry and keeps in SGPRs for the whole launch (650 SGPR spills into VGPR lanes,
-    // those VGPRs spilled in turn); hipcc 7.2 miscompiled this kernel in that regime (rocgdb: the zero high half of a
-    // 64-bit column index clobbered -> a load 48 GiB off its row).
+    // the population view is read through gen::kernarg_view (generic_blocks.h), made opaque again by NAF_PHASE() at the
+    // start of every phase (dv_arg is the first argument: offset 0)
     const RlcNafDev* dvp;
-#define NAF_PHASE() (dvp = naf_kernarg_view())
+#define NAF_PHASE() (dvp = kernarg_view<RlcNafDev>())
 #define dv (*dvp)
 #define d (dvp->d)
     NAF_PHASE();

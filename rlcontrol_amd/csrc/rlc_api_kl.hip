@@ -26,8 +26,7 @@ int rlc_kl_create(const rlc_kl_config* cfg, rlc_handle** out) {
                 "ForwardKL implements optim_type 'intg' only");
     RLC_REQUIRE(cfg->q_update_type == RLC_KL_Q_NON_SAC || cfg->q_update_type == RLC_KL_Q_SAC, "unknown q_update_type %d",
                 cfg->q_update_type);
-    RLC_REQUIRE(cfg->action_dim == 1, "action_dim %d: only the action_dim == 1 quadrature (Clenshaw-Curtis line rule) "
-                "is implemented; the sparse-grid branch (l_param) is not", cfg->action_dim);
+    RLC_REQUIRE(cfg->action_dim >= 1 && cfg->action_dim <= 6, "action_dim %d outside [1,6]", cfg->action_dim);
     const bool integral = cfg->optim_type == RLC_KL_OPTIM_INTG || cfg->optim_type == RLC_KL_OPTIM_HARD_INTG;
     RLC_REQUIRE(!integral || (cfg->n_nodes >= 1 && cfg->node_actions && cfg->node_weights),
                 "the integral updates need n_nodes >= 1 quadrature nodes and weights");
@@ -37,9 +36,10 @@ int rlc_kl_create(const rlc_kl_config* cfg, rlc_handle** out) {
         RLC_REQUIRE(cfg->kind == RLC_KL_REVERSE || cfg->entropy_scale[i] > 0.0f,
                     "agent %d: ForwardKL divides Q by entropy_scale, which must be positive", i);
     if (integral)   // atanh of the normalised node must be finite (the reference cuts the end points for this reason)
-        for (int k = 0; k < cfg->n_nodes; k++)
+        for (int k = 0; k < cfg->n_nodes * cfg->action_dim; k++)
             RLC_REQUIRE(cfg->node_actions[k] > -cfg->action_max0 && cfg->node_actions[k] < cfg->action_max0,
-                        "node %d (%g) is not strictly inside (-action_max, action_max)", k, (double)cfg->node_actions[k]);
+                        "node %d component %d (%g) is not strictly inside (-action_max, action_max)", k / cfg->action_dim,
+                        k % cfg->action_dim, (double)cfg->node_actions[k]);
     rlc_handle* h = new rlc_handle();
     int rc = rlc_h_init_common(h, RLC_ALGO_KL, cfg->device, cfg->n_agents, cfg->state_dim, cfg->action_dim,
                                cfg->batch_size, cfg->buffer_size, cfg->seed);
@@ -72,7 +72,7 @@ int rlc_kl_create(const rlc_kl_config* cfg, rlc_handle** out) {
     TRY(rlc_h_malloc(h, &dv.kl_step, NA));
     float *lp, *lq, *al, *na, *nw;
     TRY(rlc_h_malloc(h, &lp, NA)); TRY(rlc_h_malloc(h, &lq, NA)); TRY(rlc_h_malloc(h, &al, NA));
-    TRY(rlc_h_malloc(h, &na, K)); TRY(rlc_h_malloc(h, &nw, K));
+    TRY(rlc_h_malloc(h, &na, K * (size_t)cfg->action_dim)); TRY(rlc_h_malloc(h, &nw, K));
     dv.pi_lr = lp; dv.qv_lr = lq; dv.alpha = al; dv.kl_node_a = na; dv.kl_node_w = nw;
     TRY(rlc_h_malloc(h, &dv.noise_ctr, NA));
     TRY(rlc_h_malloc(h, &dv.tap_q, NA * RLC_MAX_BATCH));
@@ -88,7 +88,8 @@ int rlc_kl_create(const rlc_kl_config* cfg, rlc_handle** out) {
     hipError_t e = hipMemcpyAsync(lp, cfg->pi_lr, NA * sizeof(float), hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess) e = hipMemcpyAsync(lq, cfg->qf_vf_lr, NA * sizeof(float), hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess) e = hipMemcpyAsync(al, cfg->entropy_scale, NA * sizeof(float), hipMemcpyHostToDevice, h->st);
-    if (e == hipSuccess && K) e = hipMemcpyAsync(na, cfg->node_actions, K * sizeof(float), hipMemcpyHostToDevice, h->st);
+    if (e == hipSuccess && K)
+        e = hipMemcpyAsync(na, cfg->node_actions, K * cfg->action_dim * sizeof(float), hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess && K) e = hipMemcpyAsync(nw, cfg->node_weights, K * sizeof(float), hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     if (e != hipSuccess) {

@@ -78,7 +78,9 @@ __device__ inline void sac_policy_forward(const RlcSacDims& d, const float* th, 
                 const float raw = as + th[d.pbs + j];
                 const float log_std = clamp_ls ? fminf(fmaxf(raw, -20.0f), 2.0f)
                                                : -20.0f + 0.5f * (2.0f - (-20.0f)) * (tanhf(raw) + 1.0f);
-                u += L.eps[j] * expf(log_std);
+                // the KL agents above one action dimension sample MultivariateNormal(mean, diag_embed(std)): covariance
+                // diag(std), i.e. a standard deviation of sqrt(std) (reversekl_network.py:383-389)
+                u += L.eps[j] * ((clamp_ls && A > 1) ? sqrtf(expf(log_std)) : expf(log_std));
             }
             L.out[j] = tanhf(u) * amax0;
         }

@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib
 from ._lib import check, dptr, f64, fptr, iptr
 from .hip_pop import Population
-from .utils.quadrature import interior_action_nodes
+from .utils.quadrature import interior_action_nodes, sparse_grid_action_nodes
 
 KINDS = {"reverse": 1, "forward": 2}
 OPTIM_TYPES = {"intg": 0, "hard_intg": 1, "ll": 2, "hard_ll": 3}
@@ -54,7 +54,7 @@ class KLPopulation(Population):
 
     def __init__(self, kind, n_agents, state_dim, action_dim, actor_l1_dim, actor_l2_dim, critic_l1_dim, critic_l2_dim,
                  batch_size, buffer_size, tau, action_max0, pi_lr, qf_vf_lr, entropy_scale, seeds, n_param,
-                 optim_type="intg", q_update_type="non_sac", device=0, nodes=None):
+                 optim_type="intg", q_update_type="non_sac", device=0, nodes=None, l_param=None, action_max=None):
         if kind not in KINDS:
             raise ValueError("kind must be 'reverse' or 'forward'")
         if optim_type not in OPTIM_TYPES:
@@ -66,12 +66,20 @@ class KLPopulation(Population):
         self.dims = (self.S, self.A, int(actor_l1_dim), int(actor_l2_dim), int(critic_l1_dim), int(critic_l2_dim))
         self.layout, self.P = param_layout(*self.dims)
         if nodes is None:
-            nodes = interior_action_nodes(int(n_param), float(action_max0))
+            # one action dimension: the Clenshaw-Curtis line rule on N_param points; above it the sparse grid of level
+            # l_param, its nodes scaled by the whole action_max vector (reversekl_network.py:64-108) while the policy
+            # itself is scaled by action_max[0] (:47)
+            if self.A == 1:
+                nodes = interior_action_nodes(int(n_param), float(action_max0))
+            else:
+                if l_param is None:
+                    raise ValueError("action_dim > 1 needs l_param (the sparse grid's level)")
+                nodes = sparse_grid_action_nodes(int(l_param), self.A, action_max0 if action_max is None else action_max)
         node_a = np.ascontiguousarray(nodes[0], np.float32).reshape(-1)
         node_w = np.ascontiguousarray(nodes[1], np.float32).reshape(-1)
-        if node_a.size != node_w.size:
-            raise ValueError("nodes: actions and weights differ in length")
-        self.n_nodes = int(node_a.size)
+        if node_a.size != node_w.size * self.A:
+            raise ValueError("nodes: actions [K, action_dim] and weights [K] differ in length")
+        self.n_nodes = int(node_w.size)
         bc = lambda v: np.ascontiguousarray(np.broadcast_to(np.asarray(v, np.float32).reshape(-1), (self.n_agents,)))
         self._keep = dict(lp=bc(pi_lr), lq=bc(qf_vf_lr), al=bc(entropy_scale), na=node_a, nw=node_w,
                           seed=np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, np.uint64).reshape(-1), (self.n_agents,))))

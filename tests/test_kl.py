@@ -58,13 +58,102 @@ def test_interior_nodes_match_the_oracle_fp32_values():
     a, w = interior_action_nodes(64, 2.0)
     o = K.KLOracle("reverse", K.KlDims(*HEADLINE), K.init_params(K.KlDims(*HEADLINE), 0), 1e-3, 1e-3, 0.1, 0.01, 2.0, 64)
     assert a.dtype == np.float32 and len(a) == 62
-    assert np.array_equal(a, o.nodes.numpy()) and np.array_equal(w, o.weights.numpy())
+    assert np.array_equal(a, o.nodes.numpy().reshape(-1)) and np.array_equal(w, o.weights.numpy())
     assert np.all(np.abs(a) < 2.0)
     # the Gaussian policy's squashed density integrates to 1 under the rule when it is not too peaked
     mean, std = 0.3, 0.8
     u = np.arctanh(a.astype(np.float64) / 2.0)
     dens = np.exp(-(u - mean) ** 2 / (2 * std ** 2)) / (std * math.sqrt(2 * math.pi)) / (1 - (a / 2.0) ** 2)
     assert abs(np.sum(w * dens) - 1.0) < 1e-3
+
+
+# ----------------------------------------------------------------------------------------- action_dim > 1
+@pytest.mark.parametrize("l,A", [(5, 2), (6, 2), (5, 3)])
+def test_sparse_grid_two_constructions_and_exactness(l, A):
+    """the product's sparse grid (closed-form Clenshaw-Curtis) equals the oracle's restatement of
+    reversekl_network.py:78-108 (FFT Clenshaw-Curtis, the reference's loop); with the end points kept it is Smolyak's
+    rule: exact on every monomial of total degree <= 2 (l - A) + 1 at least"""
+    from rlcontrol_amd.utils.quadrature import sparse_grid_action_nodes
+    amax = np.linspace(1.0, 2.0, A)
+    a, w = sparse_grid_action_nodes(l, A, amax)
+    oa, ow = K.sparse_grid(l, A, amax)
+    assert a.shape == oa.shape == (len(w), A) and a.dtype == np.float32
+    assert np.array_equal(a, oa) and np.allclose(w, ow, rtol=2e-6, atol=1e-7)
+    assert np.all(np.abs(a) < amax[None, :]) and (w < 0).any()          # interior nodes; combination weights of both signs
+    af, wf = sparse_grid_action_nodes(l, A, 1.0, interior=False)
+    af, wf = af.astype(np.float64), wf.astype(np.float64)
+    import itertools
+    for deg in itertools.product(range(4), repeat=A):
+        if sum(deg) > 2 * (l - A) + 1:
+            continue
+        exact = np.prod([0.0 if p % 2 else 2.0 / (p + 1) for p in deg])
+        assert abs(np.sum(wf * np.prod(af ** np.array(deg)[None, :], 1)) - exact) < 2e-5, deg
+
+
+def test_multivariate_policy_keeps_the_reference_covariance():
+    """get_distribution: MultivariateNormal(mean, diag_embed(std)) -- the covariance is diag(std), so component j has
+    variance std_j; the oracle's draw and log-density follow that class, not N(mean, std^2)"""
+    mean, std = torch.tensor([[0.2, -0.4]]), torch.tensor([[0.25, 1.5]])
+    z = torch.tensor([[0.7, 0.1]])
+    lp = K._normal_logprob(z, mean, std)
+    want = sum(-(z[0, j] - mean[0, j]) ** 2 / (2 * std[0, j]) - 0.5 * torch.log(std[0, j]) - 0.5 * math.log(2 * math.pi)
+               for j in range(2))
+    assert lp.shape == (1, 1) and abs(lp.item() - want.item()) < 1e-6
+    assert torch.allclose(K._sample_scale(std), std.sqrt()) and torch.equal(K._sample_scale(std[:, :1]), std[:, :1])
+    torch.manual_seed(0)
+    draws = torch.distributions.MultivariateNormal(mean[0], torch.diag_embed(std[0])).sample((20000,))
+    assert torch.allclose(draws.var(0), std[0], rtol=0.05)
+
+
+MULTI = [((3, 2, 48, 40, 44, 36), 12, 5), ((4, 3, 32, 32, 32, 32), 9, 4), ((3, 2, 64, 64, 64, 64), 32, 6)]
+
+
+def _batch_a(rng, B, S, A):
+    return (rng.uniform(-2, 2, (B, S)), rng.uniform(-2, 2, (B, A)), rng.uniform(-2, 2, (B, S)),
+            rng.uniform(-16, 0, B), np.where(rng.rand(B) < 0.2, 0.0, 0.99), rng.randn(B, A))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,optim,qup", MODES)
+@pytest.mark.parametrize("dims,B,l_param", MULTI)
+def test_kl_hip_multi_dimensional_actions_match_oracle(hip_lib, kind, optim, qup, dims, B, l_param):
+    """action_dim > 1: sparse-grid nodes, the diag(std)-covariance policy, A action rows at the Q network's input"""
+    d = K.KlDims(*dims)
+    S, A = dims[0], dims[1]
+    rng = np.random.RandomState(3)
+    th = _lively(d, K.init_params(d, 1), rng)
+    amax = np.full(A, 2.0)
+    pop = _pop(kind, dims, B, optim, qup, l_param=l_param, action_max=amax)
+    assert pop.kernel_in_use() == "generic"
+    pop.enable_grad_taps(True)
+    pop.set_params(0, th)
+    o = K.KLOracle(kind, d, th, 1e-3, 1e-2, 0.3, 0.01, 2.0, 0, optim, qup, l_param=l_param, action_max=amax)
+    assert pop.n_nodes == len(o.weights)
+    lay, _ = d.layout()
+    st, e1 = rng.uniform(-2, 2, (4, S)), rng.randn(4, A)
+    for i in range(4):                                   # acting: mean action and the sqrt(std)-scaled sample
+        assert _rel(pop.act(st[i:i + 1]), o.act(st[i:i + 1])) < 1e-5
+        assert _rel(pop.act(st[i:i + 1], sample=True, eps=e1[i:i + 1]), o.act(st[i:i + 1], eps=e1[i:i + 1])) < 1e-5
+    for it in range(3):
+        s, a, s2, r, g, eps = _batch_a(rng, B, S, A)
+        pop.update_batch(0, s, a, s2, r, g, eps=eps)
+        t = o.update(s, a, s2, r, g, eps, taps=True)
+        tol = 1e-5 if it == 0 else 2e-4
+        for k in ("q", "v", "q_pi", "logp"):
+            assert _rel(pop.last_tap(0, k), t[k]) < tol, (it, k)
+        if "intgrl_q" in t:
+            assert _rel(pop.last_tap(0, "intgrl_q"), t["intgrl_q"]) < tol, it
+        assert _rel(pop.last_tap(0, "loss"), t["loss"]) < 10 * tol, it
+        if it == 0:
+            got = pop.last_tap(0, "grads")
+            for n, (off, shp) in lay.items():
+                k = int(np.prod(shp))
+                # the sparse grid's weights cancel (both signs): the policy gradient is a difference of large sums
+                bound = 3e-4 if (n[0] == "p" or k == 1) else 5e-5
+                assert _rel(got[off:off + k], t["grads"][off:off + k]) < bound, n
+            vo = lay["vW1"][0]
+            assert _rel(pop.get_blob(0, "theta_target")[vo:], o.theta_t.numpy()[vo:]) < 1e-5
+    pop.close()
 
 
 # ----------------------------------------------------------------------------------------- CPU: oracle pieces
@@ -99,7 +188,7 @@ def test_oracle_policy_gradient_matches_central_differences(kind, optim, qup):
     s, a, s2, r, g, eps = _batch(rng, B, 3)
     alpha, amax = 0.3, 2.0
     o = K.KLOracle(kind, d, th, 1e-3, 1e-3, alpha, 0.01, amax, 16, optim, qup)
-    nodes, wts = o.nodes.numpy().astype(np.float64), o.weights.numpy().astype(np.float64)
+    nodes, wts = o.nodes.numpy().reshape(-1).astype(np.float64), o.weights.numpy().astype(np.float64)
     t = o.update(s, a, s2, r, g, eps, taps=True)
     lay, _ = d.layout()
 
@@ -169,12 +258,13 @@ KERNELS = ["generic", "mfma"]
 
 
 def _pop(kind, dims, B, optim="intg", qup="non_sac", n_agents=1, alpha=0.3, cap=2048, n_param=64, pi_lr=1e-3, qv_lr=1e-2,
-         kernel="auto"):
+         kernel="auto", l_param=None, action_max=None):
     from rlcontrol_amd.hip_kl import KLPopulation
     from rlcontrol_amd._lib import RlcError
     S, A, L1A, L2A, L1C, L2C = dims
     pop = KLPopulation(kind, n_agents, S, A, L1A, L2A, L1C, L2C, B, cap, 0.01, 2.0, pi_lr, qv_lr, alpha,
-                       seeds=list(range(5, 5 + n_agents)), n_param=n_param, optim_type=optim, q_update_type=qup)
+                       seeds=list(range(5, 5 + n_agents)), n_param=n_param, optim_type=optim, q_update_type=qup,
+                       l_param=l_param, action_max=action_max)
     if kernel != "auto":
         try:
             pop.set_kernel(kernel)
@@ -332,8 +422,10 @@ def test_kl_hip_replay_path_device_sampler_and_act(hip_lib, kind, kernel):
 @pytest.mark.gpu
 def test_kl_hip_refuses_what_it_does_not_implement(hip_lib):
     from rlcontrol_amd._lib import RlcError
-    with pytest.raises(RlcError, match="action_dim"):
+    with pytest.raises(ValueError, match="l_param"):            # above one action dimension the sparse grid needs its level
         _pop("reverse", (3, 2, 32, 32, 32, 32), 8)
+    with pytest.raises(RlcError, match="action_dim"):
+        _pop("reverse", (3, 7, 32, 32, 32, 32), 8, l_param=7)
     with pytest.raises(RlcError, match="intg"):
         _pop("forward", (3, 1, 32, 32, 32, 32), 8, optim="ll")
     with pytest.raises(ValueError):
@@ -379,6 +471,37 @@ def test_kl_dropin_agent_runs_on_pendulum(hip_lib, name):
     assert agent.network_manager.population.get_step(0) == 80 - 32        # learn() once the buffer exceeds the batch
     g1, g2 = agent.start(obs, False), agent.start(obs, False)
     assert np.array_equal(g1, g2)                    # evaluation uses the mean action
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ReverseKL", "ForwardKL"])
+def test_kl_dropin_agent_takes_a_two_dimensional_action_box(hip_lib, name):
+    """action_dim 2 (no such environment can be built here: gym is absent): the agent builds the l_param sparse grid,
+    acts, stores and learns on synthetic transitions"""
+    from rlcontrol_amd.utils.config import Config
+    from rlcontrol_amd.utils.main_utils import create_agent
+    cfg = Config()
+    cfg.merge_config({"env_name": "synthetic", "state_dim": 4, "state_min": -np.ones(4), "state_max": np.ones(4),
+                      "action_dim": 2, "action_min": -np.ones(2), "action_max": np.ones(2)})
+    cfg.merge_config({"norm_type": "input_norm", "exploration_policy": "none", "actor_l1_dim": 32, "actor_l2_dim": 32,
+                      "critic_l1_dim": 32, "critic_l2_dim": 32, "pi_lr": 1e-3, "qf_vf_lr": 1e-3,
+                      "sample_for_eval": "False", "use_true_q": "False", "entropy_scale": 0.1, "l_param": 5, "N_param": 64,
+                      "optim_type": "intg", "q_update_type": "non_sac", "buffer_size": 500, "writer": None,
+                      "write_log": False, "write_plot": False, "random_seed": 0})
+    agent = create_agent(name, cfg)
+    assert agent.network_manager.population.n_nodes == 73                  # level 5 in two dimensions
+    rng = np.random.RandomState(0)
+    obs = rng.uniform(-1, 1, 4)
+    agent.reset()
+    a = agent.start(obs, True)
+    for t in range(50):
+        obs_n = rng.uniform(-1, 1, 4)
+        agent.update(obs, obs_n, float(-np.sum(a ** 2)), a, False, False)
+        a = agent.step(obs_n, True)
+        obs = obs_n
+        assert a.shape == (2,) and np.all(np.abs(a) <= 1.0)
+    assert agent.network_manager.population.get_step(0) == 50 - 32
+    assert np.all(np.isfinite(agent.network_manager.population.get_blob(0, "theta")))
 
 
 @pytest.mark.gpu
