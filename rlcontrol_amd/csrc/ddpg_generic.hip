@@ -62,13 +62,19 @@ __host__ __device__ inline size_t lds_carve(const RlcDims& d, unsigned char* bas
     return off;
 }
 
-__global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDev dv, int first_agent,
+__global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDev dv_arg, int first_agent,
                                                                            int n_updates, int source,
                                                                            const long long* host_idx,
                                                                            int grad_taps, const RlcRollout* rollout,
                                                                            int q8_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const RlcDims d = dv.d;
+    // the population view is read through gen::kernarg_view (generic_blocks.h), made opaque again by DDPG_PHASE() at the
+    // start of every phase (dv_arg is the first argument: offset 0)
+    const RlcDev* dvp;
+#define DDPG_PHASE() (dvp = kernarg_view<RlcDev>())
+#define dv (*dvp)
+#define d (dvp->d)
+    DDPG_PHASE();
     const int S = d.S, A = d.A, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
     const int agent = first_agent + blockIdx.x;
     const int tid = threadIdx.x;
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
             if (!rlc_train_step_device(rollout, agent, L.pol, u == 0 ? q8_first : 0)) continue;
         }
         // ---- sample + gather (utils/replaybuffer.py:32-37) ----
+        DDPG_PHASE();
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
             const unsigned long long call = dv.rep.sample_ctr[agent];
@@ -156,6 +163,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         __syncthreads();
 
         // ---- steps 1-2: target actor / critic on s' (DDPG.py:77) ----
+        DDPG_PHASE();
         hidden(L.x2, S, nullptr, 0, tt, d.oW1, d.ob1, d.oL1b, d.oL1g, H1, h1, nullptr, nullptr);
         hidden(h1, H1, nullptr, 0, tt, d.oWa2, d.oba2, d.oL2b, d.oL2g, HA, h2, nullptr, nullptr);
         blk_dense(h2, HA, HA, nullptr, 0, tt + d.oWa3, tt + d.oba3, A, L.mu, A, B, 2);
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         __syncthreads();
 
         // ---- step 3: critic step (hydra_ddpg_network.py:71-72) ----
+        DDPG_PHASE();
         hidden(L.x, S, nullptr, 0, th, d.oWc1, d.obc1, d.oLcb, d.oLcg, H1, c1, nc, rc);
         hidden(c1, H1, L.a, A, th, d.oWc2, d.obc2, d.oL3b, d.oL3g, HC, g2, n3, r3);
         blk_dense(g2, HC, HC, nullptr, 0, th + d.oWc3, th + d.obc3, 1, L.q, 1, B, 0);
@@ -207,6 +216,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
 
         // ---- step 4: actor forward with the updated first layer (DDPG.py:90) ----
+        DDPG_PHASE();
         hidden(L.x, S, nullptr, 0, th, d.oW1, d.ob1, d.oL1b, d.oL1g, H1, h1, n1, r1);
         hidden(h1, H1, nullptr, 0, th, d.oWa2, d.oba2, d.oL2b, d.oL2g, HA, h2, n2, r2);
         blk_dense(h2, HA, HA, nullptr, 0, th + d.oWa3, th + d.oba3, A, L.mu, A, B, 2);
@@ -218,6 +228,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         }
         __syncthreads();
         // ---- step 5: dQ/da at the scaled action with the updated critic (DDPG.py:91) ----
+        DDPG_PHASE();
         if (SEP) hidden(L.x, S, nullptr, 0, th, d.oWc1, d.obc1, d.oLcb, d.oLcg, H1, c1, nullptr, nullptr);
         hidden(c1, H1, L.aout, A, th, d.oWc2, d.obc2, d.oL3b, d.oL3g, HC, g2, n3, r3);
         if (NORM) {
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         }
         __syncthreads();
         // ---- step 6: actor step ----
+        DDPG_PHASE();
         for (int it = tid; it < B * HA; it += kThreads) {
             const int b = it / HA, n = it % HA;
             float acc = 0.0f;
@@ -266,12 +278,16 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
         __syncthreads();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
         // ---- step 7: Polyak on every tensor (hydra_ddpg_network.py:29) ----
+        DDPG_PHASE();
         for (int p = tid; p < d.Pdev; p += kThreads) {
             const float t = tt[p];
             tt[p] = t + dv.tau * (th[p] - t);
         }
         __syncthreads();
     }
+#undef DDPG_PHASE
+#undef dv
+#undef d
 }
 
 // greedy action (+ optional device OU noise) for one state per agent: predict_action on B=1

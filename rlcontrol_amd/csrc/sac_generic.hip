@@ -54,12 +54,18 @@ __host__ __device__ inline size_t slds_carve(const RlcSacDims& d, unsigned char*
     return off;
 }
 
-__global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, int first_agent, int n_updates,
+__global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv_arg, int first_agent, int n_updates,
                                                                   int source, const long long* host_idx,
                                                                   const float* eps_in, int grad_taps,
                                                                   const RlcSacRollout* rollout) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const RlcSacDims d = dv.d;
+    // the population view is read through gen::kernarg_view (generic_blocks.h), made opaque again by SAC_PHASE() at the
+    // start of every phase (dv_arg is the first argument: offset 0)
+    const RlcSacDev* dvp;
+#define SAC_PHASE() (dvp = kernarg_view<RlcSacDev>())
+#define dv (*dvp)
+#define d (dvp->d)
+    SAC_PHASE();
     const int S = d.S, A = d.A, L1A = d.L1A, L2A = d.L2A, L1C = d.L1C, L2C = d.L2C, B = d.B;
     const int agent = first_agent + blockIdx.x;
     const int tid = threadIdx.x;
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
             if (!rlc_sac_train_step_device(rollout, agent, L.pol)) continue;
         }
         // ---- sample + gather ----
+        SAC_PHASE();
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
             const unsigned long long call = dv.rep.sample_ctr[agent];
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
         if (tid == 0 && !eps_in) dv.noise_ctr[agent] = nctr + 1;
 
         // ---- forward: pi ----
+        SAC_PHASE();
         hidden(L.xc, S, nullptr, 0, th, d.pW1, d.pb1, d.pL1b, d.pL1g, L1A, ph1, pn1, rsd + 0 * RLC_MAX_BATCH);
         __syncthreads();
         hidden(ph1, L1A, nullptr, 0, th, d.pW2, d.pb2, d.pL2b, d.pL2g, L2A, ph2, pn2, rsd + 1 * RLC_MAX_BATCH);
@@ -207,6 +215,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
             dv.tap_logp[(size_t)agent * RLC_MAX_BATCH + b] = lp;
         }
         // ---- forward: Q(s,a), Q(s,pi) (raw state), V(s), V'(s') ----
+        SAC_PHASE();
         if (!NORM) {
             blk_dense(L.x, S, S, nullptr, 0, th + d.qW1, th + d.qb1, L1C, qh1, L1C, B, 1);
             blk_dense(L.xc, S, S, nullptr, 0, th + d.vW1, th + d.vb1, L1C, vh1, L1C, B, 1);
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
         }
 
         // ---- pi backward seeds: d(alpha*mean(logp) - mean(Q(s,pi))) / d(mu_raw, ls_pre) ----
+        SAC_PHASE();
         if (NORM) {
             // d Q(s,pi) / d (layer-2 linear output): the head's weights through the relu mask and the layer norm
             for (int it = tid; it < B * L2C; it += kThreads) gtmp[it] = qh2p[it] > 0.0f ? th[d.qW3 + it % L2C] : 0.0f;
@@ -293,12 +303,14 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
             L.dls[it] = dL_dlogstd * HALF_RANGE * (1.0f - L.t[it] * L.t[it]);
         }
         // ---- value backward seeds ----
+        SAC_PHASE();
         for (int b = tid; b < B; b += kThreads) {
             L.dout[b] = -((L.r[b] + L.g[b] * L.vt[b]) - L.q[b]) / (float)B;                  // dq_loss/dq
             L.vt[b] = -(L.qpi[b] - alpha_ent * mean_logp - L.v[b]) / (float)B;               // dv_loss/dv (Q9); vt reused
         }
         __syncthreads();
         // hidden-layer gradients, all with the pre-update weights
+        SAC_PHASE();
         blk_dense_bwd_input_ex(L.dmu, A, th + d.pWm, ph2, L2A, dp2, B, false);
         for (int it = tid; it < B * L2C; it += kThreads) {
             const int b = it / L2C, n = it % L2C;
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
         ln_bwd(dv1, vn1, rsd + 5 * RLC_MAX_BATCH, d.vL1g, L1C, gg[4], gb[4]);
         ln_bwd(dp1, pn1, rsd + 0 * RLC_MAX_BATCH, d.pL1g, L1A, gg[0], gb[0]);
         // ---- gradients + Adam: pi optimizer, then value optimizer (disjoint parameters) ----
+        SAC_PHASE();
         {
             const AdamCtx cp = {th, mm, vv, adam_alpha(dv.pi_lr[agent], pw[0], pw[1]), tapg};
             blk_dense_grad_adam(ph2, L2A, L2A, nullptr, 0, L.dmu, A, B, cp, d.pWm, d.pbm);
@@ -343,9 +356,13 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv, 
         __syncthreads();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; pw[2] *= 0.9f; pw[3] *= 0.999f; }
         // ---- Polyak over every main/target pair (sac_network.py:72-73): (1-tau)*target + tau*main ----
+        SAC_PHASE();
         for (int p = tid; p < d.Pdev; p += kThreads) tt[p] = (1.0f - dv.tau) * tt[p] + dv.tau * th[p];
         __syncthreads();
     }
+#undef SAC_PHASE
+#undef dv
+#undef d
 }
 
 // mean / sampled action for one state per agent (sac_network.py:327-343): one workgroup per agent
