@@ -125,22 +125,23 @@ def _make_population(agent_name, members, arg_params):
                                           c0.critic_l2_dim, m[3].random_seed), init_target=True)
         return pop
     check_norm_type(c0, agent_name + " --device_rollout",
-                    {"SoftActorCritic": ('input_norm', 'layer'), "NAF": ('none', 'input_norm', 'layer')}.get(
-                        agent_name, ('none', 'input_norm')))
+                    ('input_norm', 'layer') if agent_name == "SoftActorCritic" else ('none', 'input_norm', 'layer'))
     if agent_name == "DDPG":
         from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
         if c0.exploration_policy != 'ou_noise':
             raise RuntimeError("the device loop implements DDPG's 'ou_noise' exploration policy only")
+        separate = getattr(c0, "network", "hydra") == "separate"
         pop = DDPGPopulation(
             n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, shared_l1_dim=c0.shared_l1_dim,
             actor_l2_dim=c0.actor_l2_dim, critic_l2_dim=c0.critic_l2_dim, batch_size=c0.batch_size,
             buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min, state_max=c0.state_max,
             action_min=c0.action_min, action_max=c0.action_max, actor_lr=[m[3].actor_lr for m in members],
             critic_lr=[m[3].critic_lr for m in members], seeds=seeds, clip_state=(c0.norm_type != 'none'),
-            ou_theta=c0.ou_theta, ou_mu=c0.ou_mu, ou_sigma=c0.ou_sigma, device=device)
+            ou_theta=c0.ou_theta, ou_mu=c0.ou_mu, ou_sigma=c0.ou_sigma, device=device, norm_type=c0.norm_type,
+            separate_networks=separate)
         for i, m in enumerate(members):
             pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.shared_l1_dim, c0.actor_l2_dim,
-                                          c0.critic_l2_dim, m[3].random_seed), init_target=True)
+                                          c0.critic_l2_dim, m[3].random_seed, c0.norm_type, separate), init_target=True)
         return pop
     if agent_name == "NAF":
         from rlcontrol_amd.hip_naf import NAFPopulation, init_params

@@ -177,6 +177,16 @@ class RolloutOracle(object):
         return self
 
 
+class VariantRolloutOracle(RolloutOracle):
+    """DDPG with norm_type 'layer' and / or separate actor / critic networks in the on-device loop: the same loop around
+    oracle/ddpg_variants.py's network (dims is a VDims)"""
+
+    def _make_net(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state):
+        from .ddpg_variants import DDPGVariantOracle
+        return DDPGVariantOracle(dims, np.asarray(theta, np.float32), actor_lr, critic_lr, tau, state_min, state_max,
+                                 action_max, clip_state)
+
+
 class SacRolloutOracle(RolloutOracle):
     """One SoftActorCritic agent of the on-device loop (sac_rollout_device.h): training actions are reparameterised
     samples of the current policy, evaluation uses the mean action, no exploration-noise state."""

@@ -62,8 +62,6 @@ static int rollout_alloc(rlc_handle* h, const rlc_rollout_config* cfg) {
 int rlc_ddpg_rollout_create(rlc_handle* h, const rlc_rollout_config* cfg) {
     RLC_REQUIRE(h && cfg, "null argument");
     RLC_NEED_DDPG(h);
-    RLC_REQUIRE(!h->dv.d.norm && !h->dv.d.sep, "the on-device experiment loop implements the hydra network with "
-                "norm_type 'none' / 'input_norm' (its batched evaluation kernel has no layer-norm / separate-network path)");
     if (rollout_alloc(h, cfg)) return 1;
     // device-resident argument block of the fused launches
     if (rlc_h_malloc(h, &h->rollout_dev, 1)) return 1;

@@ -129,6 +129,46 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_eval_kernel(RlcDev dv, RlcE
     }
 }
 
+// The variants (norm_type 'layer', separate networks): one greedy test episode per workgroup through
+// ddpg_greedy_forward -- the acting kernel's own forward pass, layer norms included -- as the SAC / NAF loops do.
+__global__ __launch_bounds__(kThreads) void rlc_ddpg_eval_rows_kernel(RlcDev dv, RlcEnvDev env, int eval_round) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double sim[RLC_ENV_STATE];
+    __shared__ double obs[8];
+    __shared__ int s_done;
+    const RlcDims& d = dv.d;
+    const int S = d.S;
+    const int agent = blockIdx.x / env.eval_episodes, ep = blockIdx.x % env.eval_episodes;
+    const int tid = threadIdx.x;
+    const DdpgPolicyLds L = ddpg_policy_carve(d, (float*)smem);
+    const float* th = dv.theta + (size_t)agent * d.Ppad;
+    if (tid == 0) {
+        env_reset(env.env_id, sim, obs, dv.rep.seed[agent] ^ RLC_KEY_ENV_TEST,
+                  (unsigned long long)eval_round * env.eval_episodes + ep);
+        s_done = 0;
+    }
+    __syncthreads();
+    double ret = 0.0;
+    int steps = 0;
+    while (steps < env.episode_limit) {
+        for (int i = tid; i < S; i += kThreads) L.x[i] = clip_state_val((float)obs[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+        ddpg_greedy_forward(d, th, L, dv.amax);
+        if (tid == 0) {
+            double reward;
+            s_done = env_step(env.env_id, sim, L.act, obs, &reward, steps + 1, env.episode_limit);
+            ret += reward;
+        }
+        steps++;
+        __syncthreads();
+        if (s_done) break;
+    }
+    if (tid == 0 && eval_round < env.max_evals) {
+        const size_t at = ((size_t)agent * env.max_evals + eval_round) * env.eval_episodes + ep;
+        env.eval_ret[at] = ret;
+        env.eval_len[at] = steps;
+    }
+}
+
 static size_t eval_lds_bytes(const RlcDims& d) {
     const size_t fl = (size_t)RLC_EVAL_GROUP * (((d.S + 3) & ~3) + ((d.H1 + 3) & ~3) + ((d.HA + 3) & ~3) + ((d.A + 3) & ~3));
     return sizeof(float) * fl + sizeof(double) * RLC_EVAL_GROUP * (RLC_ENV_STATE + 8 + 1) + sizeof(int) * RLC_EVAL_GROUP * 2;
@@ -137,6 +177,12 @@ static size_t eval_lds_bytes(const RlcDims& d) {
 }  // namespace
 
 int rlc_launch_ddpg_eval(const RlcDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st) {
+    if (dv.d.norm || dv.d.sep) {
+        hipLaunchKernelGGL(rlc_ddpg_eval_rows_kernel, dim3(dv.n_agents * env.eval_episodes), dim3(kThreads),
+                           sizeof(float) * ddpg_policy_lds_floats(dv.d), st, dv, env, eval_round);
+        RLC_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t lds = eval_lds_bytes(dv.d);
     RLC_REQUIRE(lds <= 160 * 1024, "evaluation kernel needs %zu B of LDS (> 160 KiB)", lds);
     hipLaunchKernelGGL(rlc_ddpg_eval_kernel, dim3(dv.n_agents), dim3(kThreads), lds, st, dv, env, eval_round);

@@ -154,7 +154,8 @@ def test_hip_variant_update_matches_oracle(hip_lib, dims, B, norm, sep):
 
 @pytest.mark.gpu
 def test_hip_variant_replay_path_and_kernel_guard(hip_lib):
-    """fused sample + gather + update on the replay with layer norm; the MFMA kernel and the device loop refuse"""
+    """fused sample + gather + update on the replay with layer norm; the MFMA kernel refuses (the device loop runs it:
+    tests/test_gpu_rollout.py)"""
     from rlcontrol_amd._lib import RlcError
     dims, B, N = (3, 1, 200, 200, 200), 100, 512
     d = VDims(*dims, norm=True)

@@ -96,6 +96,49 @@ def test_rollout_matches_cpu_restatement(hip_lib, kernel):
         assert np.allclose(pw, orc.net.pw, rtol=1e-6)                          # same number of Adam steps
 
 
+@pytest.mark.parametrize("norm,sep", [(True, False), (False, True), (True, True)])
+def test_ddpg_variant_rollout_matches_cpu_restatement(hip_lib, norm, sep):
+    """norm_type 'layer' / separate networks in the on-device loop (train step, fused any-shape update, per-episode
+    evaluation kernel through ddpg_greedy_forward) against the loop around oracle/ddpg_variants.py"""
+    from oracle.ddpg_variants import VDims, init_params
+    from oracle.rollout import VariantRolloutOracle
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    from rlcontrol_amd.hip_ddpg import DDPGPopulation
+    dims, B = (3, 1, 32, 32, 32), 16
+    seeds, lr_a, lr_c = [11, 7777777777], [1e-3, 5e-4], [1e-2, 2e-3]
+    d = VDims(*dims, norm=norm, separate=sep)
+    pop = DDPGPopulation(2, *dims, B, 4096, 0.01, SMIN, SMAX, AMIN, AMAX, lr_a, lr_c, seeds=seeds,
+                         norm_type="layer" if norm else "input_norm", separate_networks=sep)
+    thetas = [init_params(d, 100 + i) for i in range(2)]
+    for i, th in enumerate(thetas):
+        pop.set_params(i, th, init_target=True)
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00011, "EpisodeSteps": 25,
+           "EvalIntervalMilSteps": 0.00004, "EvalEpisodes": 2}
+    exp = DeviceExperiment(pop, env, gamma=0.99, warmup_steps=0)
+    assert exp.advance(60) == 60
+    exp.advance(1000)
+    assert exp.total_steps == 110
+    res = exp.results()
+    for a in range(2):
+        orc = VariantRolloutOracle(d, thetas[a], lr_a[a], lr_c[a], 0.01, SMIN, SMAX, AMIN, AMAX, seeds[a], B, 4096,
+                                   0.99, 0, 25, 110, 40, 2).run()
+        tr, er, tl, el, ts, _, _, n_started, tc = res[a]
+        assert tl == orc.train_len == [25] * 4 and tc == orc.train_cum == [25, 50, 75, 100]
+        assert ts == orc.timesteps_at_eval == [0, 40, 80] and el == orc.eval_len and n_started == 5
+        assert pop.replay_size(a) == len(orc.replay) == 110 - 4
+        s, act, r, s2, g = pop.replay_gather(a, np.arange(106))
+        os_ = np.array([t[0] for t in orc.replay]); oa = np.array([t[1] for t in orc.replay])
+        pre = B + 1
+        assert np.allclose(s[:pre], os_[:pre], atol=2e-6) and np.allclose(act[:pre], oa[:pre], atol=2e-6)
+        assert np.allclose(s, os_, atol=3e-3) and np.allclose(act, oa, atol=3e-3)
+        assert np.allclose(er[0], orc.eval_ret[0], rtol=1e-5, atol=1e-4)      # evaluation 0: initial weights
+        assert np.allclose(er, orc.eval_ret, rtol=3e-3, atol=3e-2)
+        th = pop.get_blob(a, "theta")
+        assert np.max(np.abs(th - orc.net.theta)) < 3e-3 * np.max(np.abs(orc.net.theta))
+        assert np.allclose(pop.get_beta_powers(a), orc.net.pw, rtol=1e-6)
+    pop.close()
+
+
 def test_rollout_quirk_q8_noise_reset_after_eval(hip_lib):
     """An evaluation in the middle of a training episode resets the OU state AFTER the pending action was
     drawn (experiment.py:121-133): with eval_episodes > 0 the noise restarts from mu, with 0 it does not.
