@@ -84,7 +84,7 @@ def _run_data(random_seed, env_json, result):
 # per-agent learning rates / entropy scale and the seed)
 _SHARED_KEYS = {
     "DDPG": ("shared_l1_dim", "actor_l2_dim", "critic_l2_dim", "batch_size", "buffer_size", "tau", "gamma",
-             "warmup_steps", "norm_type", "exploration_policy", "ou_theta", "ou_mu", "ou_sigma"),
+             "warmup_steps", "norm_type", "network", "exploration_policy", "ou_theta", "ou_mu", "ou_sigma"),
     "SoftActorCritic": ("actor_l1_dim", "actor_l2_dim", "critic_l1_dim", "critic_l2_dim", "batch_size", "buffer_size",
                         "tau", "gamma", "warmup_steps", "norm_type", "exploration_policy", "sample_for_eval"),
     "NAF": ("l1_dim", "l2_dim", "batch_size", "buffer_size", "tau", "gamma", "warmup_steps", "norm_type",
