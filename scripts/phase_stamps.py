@@ -19,7 +19,8 @@ def main():
     KERN = "mfma"
     NAMES = NAMES_HBUF
     NA, U, N = int(os.environ.get("NA", "256")), 8, 200000
-    pop = DDPGPopulation(NA, 3, 1, 200, 200, 200, 100, N, 0.01, [-1, -1, -8], [1, 1, 8], [-2.0], [2.0], 1e-3, 1e-2,
+    BATCH = int(os.environ.get("B", "100"))              # B=32: the shipped jsons' batch size
+    pop = DDPGPopulation(NA, 3, 1, 200, 200, 200, BATCH, N, 0.01, [-1, -1, -8], [1, 1, 8], [-2.0], [2.0], 1e-3, 1e-2,
                          seeds=np.arange(NA) + 1)
     pop.set_kernel(KERN)
     pop.enable_grad_taps(True)
