@@ -280,6 +280,10 @@ int rlc_kl_enable_grad_taps(rlc_kl* h, int32_t on);
  * [16,256], batch_size <= 32, at most 256 nodes, LDS permitting) */
 int rlc_kl_set_kernel(rlc_kl* h, int32_t variant);
 int rlc_kl_get_kernel(const rlc_kl* h, int32_t* variant_in_use);
+/* latency mode, as rlc_ddpg_set_split: n_workgroups (1..8) CUs per agent.  The forward passes of Q at the (state, node)
+ * pairs of the action integral -- two thirds of an update -- are dealt over them; results are bit-identical to the
+ * one-workgroup kernel's.  MFMA kernel and the integral updates only; host loop only; the GPU must not be shared. */
+int rlc_kl_set_split(rlc_kl* h, int32_t n_workgroups);
 
 
 /* ===================================== NAF =========================================================

@@ -30,7 +30,7 @@ EXPORTS = (
     "rlc_sac_last_tap", "rlc_sac_enable_grad_taps", "rlc_sac_set_kernel", "rlc_sac_get_kernel",
     "rlc_kl_create", "rlc_kl_param_count", "rlc_kl_set_blob", "rlc_kl_get_blob", "rlc_kl_set_step", "rlc_kl_get_step",
     "rlc_kl_init_target", "rlc_kl_act", "rlc_kl_update", "rlc_kl_update_batch", "rlc_kl_last_tap",
-    "rlc_kl_enable_grad_taps", "rlc_kl_set_kernel", "rlc_kl_get_kernel",
+    "rlc_kl_enable_grad_taps", "rlc_kl_set_kernel", "rlc_kl_get_kernel", "rlc_kl_set_split",
     "rlc_naf_create", "rlc_naf_param_count", "rlc_naf_set_blob", "rlc_naf_get_blob", "rlc_naf_get_beta_powers",
     "rlc_naf_init_target", "rlc_naf_act", "rlc_naf_update", "rlc_naf_update_batch", "rlc_naf_last_tap",
     "rlc_naf_enable_grad_taps", "rlc_naf_set_kernel", "rlc_naf_get_kernel",

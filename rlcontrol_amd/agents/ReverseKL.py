@@ -42,6 +42,11 @@ class KL_Network_Manager(BaseNetwork_Manager):
         theta0 = init_params(config.state_dim, config.action_dim, config.actor_l1_dim, config.actor_l2_dim,
                              config.critic_l1_dim, config.critic_l2_dim, config.random_seed)
         self.population.set_params(0, theta0, init_target=True)
+        # optional json key "hip_split": latency mode, this one agent's action integral over that many CUs (the GPU must
+        # not be shared while it learns; rlc_kl_set_split)
+        split = int(getattr(config, "hip_split", 1))
+        if split > 1:
+            self.population.set_split(split)
 
     def device_replay(self):
         return (self.population, 0)

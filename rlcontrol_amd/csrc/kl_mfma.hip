@@ -20,3 +20,18 @@ int rlc_launch_kl_update_mfma(const RlcSacDev& dv, int first_agent, int n_agents
     RLC_REQUIRE(dv.d.blocked, "the MFMA kernel reads tile-blocked weights (rlc_kl_set_kernel re-packs them)");
     return kl_launch_t<2, 7>(dv, first_agent, n_agents, n_updates, source, idx_dev, eps_dev, grad_taps, st, rollout);
 }
+
+// latency mode: the node passes of every agent's action integral dealt over C workgroups (kl_mfma_kernel.h)
+size_t rlc_kl_split_zbuf_floats(const RlcSacDims& d) { return (size_t)32 * kl_mfma_ldh(d); }
+int rlc_kl_split_grid(int n_agents, int C) { return kl_split_grid(n_agents, C); }
+
+int rlc_launch_kl_update_mfma_split(const RlcSacDev& dv, float* zbuf, unsigned int* bar, int* err, int C, int first_agent,
+                                    int n_agents, int n_updates, int source, const long long* idx_dev, const float* eps_dev,
+                                    int grad_taps, hipStream_t st) {
+    RLC_REQUIRE(rlc_kl_mfma_supported(dv.d, dv.kl_nodes), "MFMA KL kernel does not support these dimensions");
+    RLC_REQUIRE(dv.d.blocked, "the MFMA kernel reads tile-blocked weights (rlc_kl_set_kernel re-packs them)");
+    RLC_REQUIRE(dv.kl_optim == RLC_KL_OPTIM_INTG || dv.kl_optim == RLC_KL_OPTIM_HARD_INTG,
+                "latency mode splits the action integral; the 'll' updates have none");
+    const KlSplit sp = {zbuf, bar, err, C, n_agents};
+    return kl_launch_split_t<2, 7>(dv, sp, first_agent, n_updates, source, idx_dev, eps_dev, grad_taps, st);
+}

@@ -32,6 +32,43 @@ constexpr int KL_NTW = 2;
 constexpr int KL_MSTRIDE = mask_stride(16);
 constexpr int KL_MAXNODES = 256;
 
+// ---- latency mode (rlc_kl_set_split): the node passes of ONE agent's action integral dealt over C workgroups ----
+// Two thirds of an update are the ceil(B K / 112) forward passes of Q at the (state, node) pairs, and they are independent
+// of each other.  Workgroup 0 of an agent (the owner) runs the whole update as the one-workgroup kernel does; workgroups
+// 1..C-1 (helpers) only take their share of the passes: per update the owner publishes the first-layer image z1s
+// (global, [MB][LDH]) -> BARRIER -> every workgroup runs the passes p with p mod C == its index and writes Q at those
+// rows to the agent's iq buffer -> BARRIER -> the owner carries on.  The arithmetic of a pass does not depend on who
+// runs it, so the result is bit-identical to the one-workgroup kernel's.  Hand-off as in ddpg_split_kernel.h: stores
+// drained, workgroup barrier, agent-scope release, relaxed arrival counter, bounded L1-bypassing poll (a timeout sets
+// the error word instead of hanging), agent-scope acquire, workgroup barrier.  blockIdx = x + 8 (c + C y): the C
+// workgroups of agent 8y + x share XCD x (one L2 holds the weights and the exchange).
+struct KlSplit {
+    float* zbuf;            // [n_agents][MB * LDH] first-layer image of the minibatch (owner -> helpers)
+    unsigned int* bar;      // [n_agents] monotonic arrival counters, zero at launch
+    int* err;               // [1] set when a barrier poll timed out
+    int C, n_agents;
+};
+
+__device__ __forceinline__ void kl_group_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gen += 1;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int target = gen * (unsigned int)C;
+        int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 22)) { atomicExch(err, 1); break; }      // ~seconds: a peer is not resident
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 struct KSmem {
     lds_f32* hbuf;                       // [MBQ][LDH] (+16): activation image of the GEMM in flight
     lds_u8* mask;                        // [MB][MSTRIDE] bit 0: pi hidden (later V hidden), bit 1: Q(s,a) hidden
@@ -106,11 +143,11 @@ __device__ __forceinline__ float kl_wave_sum(float v) {
     return v;
 }
 
-template <int MT, int MTQ>
+template <int MT, int MTQ, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev dv, int first_agent, int n_updates,
                                                                       int source, const long long* host_idx,
                                                                       const float* eps_in, int grad_taps,
-                                                                      const RlcSacRollout* rollout) {
+                                                                      const RlcSacRollout* rollout, KlSplit sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using U = Blk<MT, KL_NTW, KL_MSTRIDE, true, true>;      // the three small networks: LERP target update, torch Adam
     using UQ = Blk<MTQ, KL_NTW, KL_MSTRIDE, true, true>;    // the node passes (forward only)
@@ -128,7 +165,16 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
     uq.L.hbuf = L.hbuf; uq.L.mask = L.mask; uq.L.xbuf = L.xbuf;
     const int tid = u.tid, S = d.S, L1A = d.L1A, L2A = d.L2A, L1C = d.L1C, L2C = d.L2C, B = d.B, K = dv.kl_nodes;
     const int LDH = u.LDH;
-    const int agent = first_agent + blockIdx.x;
+    // SPLIT: workgroup -> (agent, c), the C workgroups of an agent on one XCD; c == 0 owns the update
+    int c_split = 0, rel_agent = blockIdx.x;
+    if constexpr (SPLIT) {
+        const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+        c_split = jj % sp.C;
+        rel_agent = (jj / sp.C) * 8 + xcd;
+        if (rel_agent >= sp.n_agents) return;       // whole workgroups of a padded grid: no barrier includes them
+    }
+    const int agent = first_agent + rel_agent;
+    unsigned int bar_gen = 0;
     float* th = dv.theta + (size_t)agent * d.Ppad;
     float* tt = dv.theta_t + (size_t)agent * d.Ppad;
     float* mm = dv.m + (size_t)agent * d.Ppad;
@@ -161,6 +207,59 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
     if (tid < 16) L.hbuf[(MBQ > MB ? MBQ : MB) * LDH + tid] = 0.0f;
     __syncthreads();
 
+    // Q at the rows [p0, p0 + 16 MTQ) of the B x K (state, node) grid for every pass p0 this workgroup takes (SPLIT: pass
+    // index mod C == c_split): layer 1 = relu(z1s[b] + a_k W1[action row]) written straight into the activation image
+    const int NQ = LDH >> 2;                           // column quads of a row of the activation image
+    auto node_passes = [&]() {
+        const int cq = tid % NQ, r0t = tid / NQ, rstep = kThreads / NQ;
+        const bool filler = tid < rstep * NQ;
+        const f32x4 wa = *reinterpret_cast<const lds_f32x4*>(&L.w1a[cq << 2]);
+        const float qb3 = th[d.qb3];
+        for (int p0 = 0; p0 < rows; p0 += MBQ) {
+            if (SPLIT && (p0 / MBQ) % sp.C != c_split) continue;
+            const int nr = min(MBQ, rows - p0);
+            if (filler)
+                for (int i = r0t; i < MBQ; i += rstep) {
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    if (i < nr) {
+                        const int rho = p0 + i, b = rho / K, k = rho - b * K;
+                        const f32x4 zz = *reinterpret_cast<const lds_f32x4*>(&L.z1s[b * LDH + (cq << 2)]);
+                        const float ak = L.node_a[k];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) o[e] = fmaxf(zz[e] + ak * wa[e], 0.0f);
+                    }
+                    *reinterpret_cast<lds_f32x4*>(&L.hbuf[i * LDH + (cq << 2)]) = o;
+                }
+            __syncthreads();
+            f32x4 accn[MTQ][NTW];
+            uq.fwd_gemm(accn, th + d.qW2, L2C, L1C);
+            uq.template bias_relu<0>(accn, th + d.qb2, L2C);
+            uq.template row_dot<false, 1>(accn, L2C, [&](int n, int) { return th[d.qW3 + n]; }, L.part_q);
+            __syncthreads();
+            for (int i = tid; i < nr; i += kThreads) {
+                const float qv = uq.template part_sum<1>(L.part_q, i, 0) + qb3;
+                iq[p0 + i] = qv;
+                dv.kl_tap_iq[(size_t)agent * rows + p0 + i] = qv;
+            }
+        }
+    };
+    if constexpr (SPLIT) {
+        if (c_split > 0) {
+            // helper: per update, the owner's z1s image and the current Q weights -> my passes
+            float* zb = sp.zbuf + (size_t)rel_agent * MB * LDH;
+            for (int upd = 0; upd < n_updates; upd++) {
+                kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);
+                for (int i = tid; i < (MB * LDH) >> 2; i += kThreads)
+                    reinterpret_cast<lds_f32x4*>(L.z1s)[i] = reinterpret_cast<const f32x4*>(zb)[i];
+                for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;
+                __syncthreads();
+                node_passes();
+                kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);
+            }
+            return;
+        }
+    }
+
     f32x4 acc[MT][NTW];
     for (int upd = 0; upd < n_updates; upd++) {
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));     // see ddpg_mfma_kernel.h
@@ -176,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
             rlc_sample_distinct(ring.size, B, dv.rep.seed[agent], call, L.pool, L.idx, L.dups);
             if (tid == 0) dv.rep.sample_ctr[agent] = call + 1;
         } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
-            for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + upd) * B + b];
+            for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)rel_agent * n_updates + upd) * B + b];
         }
         __syncthreads();
         const unsigned long long nctr = dv.noise_ctr[agent];
@@ -201,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
             L.xq[b * SMAX + S] = pa[0];
             float e;
             if (eps_in) {
-                e = eps_in[((size_t)blockIdx.x * n_updates + upd) * B + b];
+                e = eps_in[((size_t)rel_agent * n_updates + upd) * B + b];
             } else {
                 const Philox4 p = philox4x32_10(dv.rep.seed[agent] ^ RLC_KEY_SAC_EPS, nctr, (unsigned long long)b >> 1);
                 float n0, n1;
@@ -332,7 +431,6 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
         float pl = 0.0f;
         if (integral) {
             // ================= 6: Q at the quadrature nodes =================
-            const int NQ = LDH >> 2;                           // column quads of a row of the activation image
             // z1s[b] = s_b W1[:S] + b1 (no relu), the action row of W1
             for (int e = tid; e < B * NQ; e += kThreads) {
                 const int b = e / NQ, n0 = (e % NQ) << 2;
@@ -343,39 +441,13 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
                         o += L.x[b * SMAX + i] * *reinterpret_cast<const f32x4*>(&th[d.qW1 + i * L1C + n0]);
                 }
                 *reinterpret_cast<lds_f32x4*>(&L.z1s[b * LDH + n0]) = o;
+                if constexpr (SPLIT) *reinterpret_cast<f32x4*>(&sp.zbuf[(size_t)rel_agent * MB * LDH + b * LDH + n0]) = o;
             }
             for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;
             __syncthreads();
-            const int cq = tid % NQ, r0t = tid / NQ, rstep = kThreads / NQ;
-            const bool filler = tid < rstep * NQ;
-            const f32x4 wa = *reinterpret_cast<const lds_f32x4*>(&L.w1a[cq << 2]);
-            const float qb3 = th[d.qb3];
-            for (int p0 = 0; p0 < rows; p0 += MBQ) {
-                const int nr = min(MBQ, rows - p0);
-                if (filler)
-                    for (int i = r0t; i < MBQ; i += rstep) {
-                        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                        if (i < nr) {
-                            const int rho = p0 + i, b = rho / K, k = rho - b * K;
-                            const f32x4 zz = *reinterpret_cast<const lds_f32x4*>(&L.z1s[b * LDH + (cq << 2)]);
-                            const float ak = L.node_a[k];
-#pragma unroll
-                            for (int e = 0; e < 4; e++) o[e] = fmaxf(zz[e] + ak * wa[e], 0.0f);
-                        }
-                        *reinterpret_cast<lds_f32x4*>(&L.hbuf[i * LDH + (cq << 2)]) = o;
-                    }
-                __syncthreads();
-                f32x4 accn[MTQ][NTW];
-                uq.fwd_gemm(accn, th + d.qW2, L2C, L1C);
-                uq.template bias_relu<0>(accn, th + d.qb2, L2C);
-                uq.template row_dot<false, 1>(accn, L2C, [&](int n, int) { return th[d.qW3 + n]; }, L.part_q);
-                __syncthreads();
-                for (int i = tid; i < nr; i += kThreads) {
-                    const float qv = uq.template part_sum<1>(L.part_q, i, 0) + qb3;
-                    iq[p0 + i] = qv;
-                    dv.kl_tap_iq[(size_t)agent * rows + p0 + i] = qv;
-                }
-            }
+            if constexpr (SPLIT) kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);     // z1s published
+            node_passes();
+            if constexpr (SPLIT) kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);     // every pass has landed
             __syncthreads();
             // ================= 7: one wave per state: log pi at the nodes, d loss / d lp, seeds of mean and log_std =================
             for (int b = u.wave; b < B; b += kWaves) {
@@ -597,12 +669,33 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
     }
 }
 
+// workgroups of the latency-mode grid: agents padded to the 8 XCDs, C per agent
+inline int kl_split_grid(int n_agents, int C) { return (n_agents + 7) / 8 * 8 * C; }
+
+template <int MT, int MTQ>
+int kl_launch_split_t(const RlcSacDev& dv, const KlSplit& sp, int first_agent, int n_updates, int source,
+                      const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st) {
+    const size_t lds = ksmem_carve(dv.d, MT, MTQ, nullptr, nullptr);
+    RLC_REQUIRE(lds <= 160 * 1024, "MFMA KL kernel needs %zu B of LDS (> 160 KiB)", lds);
+    auto kern = rlc_kl_update_mfma_kernel<MT, MTQ, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    RLC_HIP(hipMemsetAsync(sp.bar, 0, sizeof(unsigned int) * sp.n_agents, st));
+    hipLaunchKernelGGL(kern, dim3(kl_split_grid(sp.n_agents, sp.C)), dim3(kThreads), lds, st, dv, first_agent, n_updates,
+                       source, idx_dev, eps_dev, grad_taps, (const RlcSacRollout*)nullptr, sp);
+    RLC_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int MT, int MTQ>
 int kl_launch_t(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
                 const float* eps_dev, int grad_taps, hipStream_t st, const RlcSacRollout* rollout) {
     const size_t lds = ksmem_carve(dv.d, MT, MTQ, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "MFMA KL kernel needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = rlc_kl_update_mfma_kernel<MT, MTQ>;
+    auto kern = rlc_kl_update_mfma_kernel<MT, MTQ, false>;
     static bool attr_set = false;
     if (!attr_set) {
         RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -610,7 +703,7 @@ int kl_launch_t(const RlcSacDev& dv, int first_agent, int n_agents, int n_update
     }
     RLC_REQUIRE(!(rollout && eps_dev), "the on-device loop draws its own eps");
     hipLaunchKernelGGL(kern, dim3(n_agents), dim3(kThreads), lds, st, dv, first_agent, n_updates, source, idx_dev, eps_dev,
-                       grad_taps, rollout);
+                       grad_taps, rollout, KlSplit{nullptr, nullptr, nullptr, 1, n_agents});
     RLC_HIP(hipGetLastError());
     return 0;
 }

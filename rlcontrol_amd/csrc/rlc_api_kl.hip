@@ -126,7 +126,31 @@ int rlc_kl_set_kernel(rlc_handle* h, int32_t variant) {
     RLC_REQUIRE(variant != 2 || rlc_kl_mfma_supported(h->sac.d, h->sac.kl_nodes),
                 "MFMA KL kernel does not support these dimensions");
     h->variant = variant;
+    if (rlc_h_kl_variant(h) != 2) h->split_c = 1;        // latency mode belongs to the MFMA kernel
     return rlc_h_sac_relayout(h, rlc_h_kl_variant(h) == 2 ? 1 : 0);
+}
+
+int rlc_kl_set_split(rlc_handle* h, int32_t n_workgroups) {
+    RLC_REQUIRE(h, "null handle");
+    RLC_NEED_KL(h);
+    if (rlc_h_use_device(h)) return 1;
+    RLC_REQUIRE(n_workgroups >= 1 && n_workgroups <= 8, "workgroups per agent must be in [1,8]");
+    RLC_REQUIRE(!h->has_env, "the on-device experiment loop runs the one-workgroup kernels");
+    if (n_workgroups == 1) { h->split_c = 1; return 0; }
+    RLC_REQUIRE(rlc_h_kl_variant(h) == 2, "latency mode is a variant of the MFMA kernel (these dimensions run the any-shape one)");
+    RLC_REQUIRE(h->sac.kl_optim == RLC_KL_OPTIM_INTG || h->sac.kl_optim == RLC_KL_OPTIM_HARD_INTG,
+                "latency mode splits the action integral; the 'll' updates have none");
+    hipDeviceProp_t prop;
+    RLC_HIP(hipGetDeviceProperties(&prop, h->device));
+    const int grid = rlc_kl_split_grid(h->sac.n_agents, n_workgroups);
+    RLC_REQUIRE(grid <= prop.multiProcessorCount, "%d agents x %d workgroups need %d co-resident workgroups; the GPU has %d CUs",
+                h->sac.n_agents, n_workgroups, grid, prop.multiProcessorCount);
+    if (!h->split_bar) {
+        if (rlc_h_malloc(h, &h->split_bar, (size_t)h->sac.n_agents) || rlc_h_malloc(h, &h->split_err, (size_t)1)) return 1;
+        if (rlc_h_malloc(h, &h->split_part, (size_t)h->sac.n_agents * rlc_kl_split_zbuf_floats(h->sac.d))) return 1;
+    }
+    h->split_c = n_workgroups;
+    return 0;
 }
 
 int rlc_kl_get_kernel(const rlc_handle* h, int32_t* variant_in_use) {

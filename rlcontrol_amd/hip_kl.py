@@ -109,6 +109,10 @@ class KLPopulation(Population):
         if init_target:
             check(self._lib.rlc_kl_init_target(self._h, int(agent)))
 
+    def set_split(self, n_workgroups):
+        """latency mode: the node passes of each agent's action integral over that many CUs (1 = off)"""
+        check(self._lib.rlc_kl_set_split(self._h, ctypes.c_int32(int(n_workgroups))))
+
     def get_step(self, agent):
         out = ctypes.c_int32(0)
         check(self._lib.rlc_kl_get_step(self._h, int(agent), ctypes.byref(out)))

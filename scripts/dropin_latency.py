@@ -2,7 +2,7 @@
 """The reference's own deployment unit -- ONE drop-in agent driven step by step from the host (main.py without
 --device_rollout) -- on one MI355X: wall time per environment step, split into env.step, agent.update (replay add +
 index draw + fused update launch) and agent.step (acting kernel round trip), for the five agents at the shipped batch
-size 32 and at BASELINE's 100, DDPG also in latency mode (json key hip_split).  Writes gpurun_out/<tag>_dropin_latency.json.
+size 32 and at BASELINE's 100, DDPG and the KL agents also in latency mode (json key hip_split).  Writes gpurun_out/<tag>_dropin_latency.json.
     python scripts/dropin_latency.py --tag r02c"""
 import argparse
 import json
@@ -78,9 +78,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--skip", type=int, default=500)
     ap.add_argument("--tag", default="r02c")
+    ap.add_argument("--only", default="", help="comma-separated agent names")
     a = ap.parse_args()
     res = {"steps_timed": a.steps - a.skip, "environment": "Pendulum-v0 (host numpy simulator)", "rows": []}
-    cases = [(n, b, {}) for n in AGENTS for b in (32, 100)] + [("DDPG", b, {"hip_split": c}) for b, c in ((32, 2), (100, 7))]
+    cases = [(n, b, {}) for n in AGENTS for b in (32, 100)] + [("DDPG", b, {"hip_split": c}) for b, c in ((32, 2), (100, 7))] + \
+            [(n, 32, {"hip_split": 8}) for n in ("ReverseKL", "ForwardKL")]
+    if a.only:
+        cases = [c for c in cases if c[0] in a.only.split(",")]
     for name, batch, extra in cases:
         r = measure(name, batch, extra, a.steps, a.skip)
         r.update(agent=name, batch=batch, **extra)

@@ -420,6 +420,89 @@ def test_kl_hip_replay_path_device_sampler_and_act(hip_lib, kind, kernel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", K.KINDS)
+@pytest.mark.parametrize("C,n_agents,n_param", [(2, 3, 64), (4, 1, 64), (8, 2, 64), (8, 9, 130), (7, 1, 9)])
+def test_kl_latency_mode_equals_one_workgroup(hip_lib, kind, C, n_agents, n_param):
+    """rlc_kl_set_split deals the node passes of the action integral over C workgroups per agent; the arithmetic of a pass
+    does not depend on who runs it, so Q at the nodes equals the one-workgroup kernel's BIT FOR BIT and everything
+    downstream to the last bit or two (the same source in a second kernel instantiation: the compiler's fma contraction
+    choices may differ) -- host indices, device sampler, staged minibatch; more agents than XCDs; fewer passes than
+    workgroups"""
+    from oracle.cpu_baseline import synthetic_pendulum_replay
+    from rlcontrol_amd._lib import RlcError
+    dims, B, N = HEADLINE, 32, 1024
+    d = K.KlDims(*dims)
+    rng = np.random.RandomState(7)
+    s, a, r, s2, g = synthetic_pendulum_replay(N, 0)
+    pops = []
+    for split in (1, C):
+        pop = _pop(kind, dims, B, n_agents=n_agents, cap=N, n_param=n_param, kernel="mfma")
+        for i in range(n_agents):
+            pop.set_params(i, _lively(d, K.init_params(d, 10 + i), np.random.RandomState(i)))
+            pop.replay_add_batch(i, s, a, r, s2, g)
+        pop.set_split(split)
+        pops.append(pop)
+    idx = np.stack([rng.choice(N, B, replace=False) for _ in range(3 * n_agents)]).reshape(n_agents, 3, B).astype(np.int64)
+    eps = rng.randn(n_agents, 3, B, 1)
+    mb = (rng.uniform(-2, 2, (B, 3)), rng.uniform(-2, 2, (B, 1)), rng.uniform(-2, 2, (B, 3)), rng.uniform(-16, 0, B),
+          np.full(B, 0.99), rng.randn(B, 1))
+    for pop in pops:
+        pop.update(3, host_indices=idx, eps=eps)          # K updates in one launch: 2 barriers each
+        pop.update(2)                                     # device sampler + device eps
+        pop.update_batch(n_agents - 1, *mb[:5], eps=mb[5])
+    one, many = pops
+    for i in range(n_agents):
+        for blob in ("theta", "theta_target", "adam_m", "adam_v"):
+            x, y = one.get_blob(i, blob).astype(np.float64), many.get_blob(i, blob).astype(np.float64)
+            assert np.max(np.abs(x - y)) <= 3e-5 * np.max(np.abs(x)) + 1e-9, (i, blob)     # six Adam steps amplify a last-bit difference
+        assert one.get_step(i) == many.get_step(i)
+    for name in ("q", "v", "q_pi", "logp", "intgrl_q"):
+        assert _rel(many.last_tap(n_agents - 1, name), one.last_tap(n_agents - 1, name)) < 1e-5, name
+    assert _rel(many.last_tap(n_agents - 1, "loss"), one.last_tap(n_agents - 1, "loss")) < 1e-5
+    # one update from identical parameters: the integral itself is bit-identical
+    th = [one.get_blob(i, "theta") for i in range(n_agents)]
+    for pop in pops:
+        for i in range(n_agents):
+            pop.set_params(i, th[i])
+        pop.update(1, host_indices=idx[:, :1], eps=eps[:, :1])
+    for i in range(n_agents):
+        assert np.array_equal(one.last_tap(i, "intgrl_q"), many.last_tap(i, "intgrl_q")), i
+    many.set_split(1)                                     # back to one workgroup on the same handle: the same kernel again
+    for pop in pops:
+        for i in range(n_agents):
+            pop.set_params(i, th[i])
+            pop.set_blob(i, "adam_m", np.zeros_like(th[i])); pop.set_blob(i, "adam_v", np.zeros_like(th[i]))
+            pop.set_step(i, 0)
+        pop.update(1, host_indices=idx[:, :1], eps=eps[:, :1])
+    assert np.array_equal(one.get_blob(0, "theta"), many.get_blob(0, "theta"))
+    for pop in pops:
+        pop.close()
+
+
+@pytest.mark.gpu
+def test_kl_latency_mode_refusals(hip_lib):
+    from rlcontrol_amd._lib import RlcError
+    pop = _pop("reverse", HEADLINE, 32, optim="ll", kernel="mfma")
+    with pytest.raises(RlcError, match="integral"):
+        pop.set_split(4)
+    pop.close()
+    pop = _pop("reverse", HEADLINE, 32, kernel="generic")
+    with pytest.raises(RlcError, match="MFMA"):
+        pop.set_split(4)
+    pop.close()
+    pop = _pop("forward", HEADLINE, 32, n_agents=40, kernel="mfma")
+    with pytest.raises(RlcError, match="co-resident"):
+        pop.set_split(8)                                   # 40 agents x 8 workgroups > 256 CUs
+    with pytest.raises(RlcError):
+        pop.set_split(9)
+    pop.set_split(4)
+    pop.set_kernel("generic")                              # leaving the MFMA kernel leaves latency mode
+    pop.update_batch(0, np.zeros((32, 3)), np.zeros((32, 1)), np.zeros((32, 3)), np.zeros(32), np.ones(32), eps=np.zeros((32, 1)))
+    assert np.all(np.isfinite(pop.get_blob(0, "theta")))
+    pop.close()
+
+
+@pytest.mark.gpu
 def test_kl_hip_refuses_what_it_does_not_implement(hip_lib):
     from rlcontrol_amd._lib import RlcError
     with pytest.raises(ValueError, match="l_param"):            # above one action dimension the sparse grid needs its level
