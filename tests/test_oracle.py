@@ -113,3 +113,39 @@ def test_critic_layout_against_reference_checkpoint(golden_dir):
     assert abs(q[acts < 0].max() - 1.0) < 0.05 and abs(q[acts > 0].max() - 1.5) < 0.05
     # Adam accumulators in the checkpoint (Q2): pinned bit for bit in tests/test_ckpt_pins.py (fp32 running product)
     assert float(ck["beta1_power"]) == 0.0 and np.float32(ck["beta2_power"]) == np.float32(4.5134042e-05)
+
+
+# ---- the CPU restatements of the on-device experiment loop run on their own (the GPU tests hold the kernels to them) ----
+SMIN, SMAX, AMAX = np.array([-1.0, -1.0, -8.0]), np.array([1.0, 1.0, 8.0]), np.array([2.0])
+
+
+def _loop_invariants(orc, total, interval, episodes, limit):
+    assert orc.total == total and len(orc.replay) == total - total // limit         # the truncating step is not stored
+    assert orc.timesteps_at_eval == list(range(0, total, interval))
+    assert all(len(e) == episodes for e in orc.eval_ret) and np.all(np.isfinite(np.array(orc.eval_ret)))
+    assert all(n == limit for n in orc.train_len) and np.all(np.isfinite(np.array(orc.train_ret)))
+    acts = np.array([t[1] for t in orc.replay])
+    assert np.all(np.abs(acts) <= 2.0) and acts.std() > 0
+
+
+@pytest.mark.parametrize("norm,sep", [(True, False), (False, True), (True, True)])
+def test_variant_rollout_oracle_runs_the_experiment_loop(norm, sep):
+    from oracle.ddpg_variants import VDims, init_params
+    from oracle.rollout import VariantRolloutOracle
+    d = VDims(3, 1, 16, 16, 16, norm=norm, separate=sep)
+    orc = VariantRolloutOracle(d, init_params(d, 1), 1e-3, 1e-2, 0.01, SMIN, SMAX, -AMAX, AMAX, 5, 8, 512, 0.99, 0, 20, 70, 30,
+                               2).run()
+    _loop_invariants(orc, 70, 30, 2, 20)
+    assert orc.n_updates >= len(orc.replay) - 8 and not np.array_equal(orc.net.theta, init_params(d, 1))
+
+
+def test_naf_layer_norm_rollout_oracle_runs_the_experiment_loop():
+    from oracle.naf import NafDims
+    from oracle.naf_variants import init_params
+    from oracle.rollout import NafRolloutOracle
+    dims = (3, 1, 16, 16)
+    th = init_params(dims, 1, True)
+    orc = NafRolloutOracle(NafDims(*dims), th, 1e-3, 0.01, SMIN, SMAX, AMAX, 0.3, 5, 8, 512, 0.99, 0, 20, 70, 30, 2,
+                           norm_type="layer").run()
+    _loop_invariants(orc, 70, 30, 2, 20)
+    assert orc.n_updates >= len(orc.replay) - 8 and not np.array_equal(orc.net.theta.numpy(), th)
