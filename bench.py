@@ -199,7 +199,7 @@ def reduce_over_ranks(dt, result, dist=None, world=1, device="cpu"):
     import torch
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     res = torch.tensor([float(result)], dtype=torch.float64, device=device)
-    if dist is None or world == 1:
+    if dist is None:
         return float(t.item()), [float(res.item())]
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     gathered = [torch.zeros_like(res) for _ in range(world)]
@@ -291,6 +291,9 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal of the N > 1 path where fewer GPUs than ranks exist: rank r uses GPU r %% n_gpus "
                          "(needs --backend gloo; the value is then NOT a scaling measurement and says so)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group at world size 1 too (one rank under torch.distributed.run): barrier, "
+                         "MAX all-reduce and all-gather then go through RCCL -- the one-GPU rehearsal of --gpus 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="skip the SAC / NAF sub-records")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -321,7 +324,7 @@ def main():
         local_rank = local_rank % max(1, torch.cuda.device_count())      # device_count() does not initialise the GPU
     torch.cuda.set_device(local_rank)          # before any other GPU call; no re-exec anywhere in this file
     dist = None
-    if world > 1:
+    if world > 1 or (args.force_dist and "RANK" in os.environ):
         import torch.distributed as dist
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -347,13 +350,13 @@ def main():
     # synthetic replay -> HBM (torch is only the allocator/copy engine here), then into every agent's ring
     _fill_from_host(pop, synthetic_pendulum_replay(REPLAY_N, 0), torch)
 
+    kernel = pop.kernel_in_use()
+    if args.split > 1:
+        pop.set_split(args.split)          # latency mode is part of what is timed
+        kernel += "+split%d" % args.split
     dt, ev_ms = measure(pop, U, args.steps, args.warmup, dist, torch.cuda.synchronize)
     red_dev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
     dt_max, gathered = reduce_over_ranks(dt, float(np.mean(pop.last_tap(0, "q"))), dist, world, red_dev)
-    kernel = pop.kernel_in_use()
-    if args.split > 1:
-        pop.set_split(args.split)
-        kernel += "+split%d" % args.split
     pop.close()
 
     if rank == 0:
@@ -383,13 +386,15 @@ def main():
             "roofline": roof,
             "roofline_hbm": roof_hbm,
         }
+        if dist is not None:
+            out["config"]["collectives"] = "%s: barrier x2, all_reduce(MAX) x1, all_gather x1 over %d rank(s)" % (
+                dist.get_backend(), world)
         out["cpu_baseline"] = cpu_base
         if world == 1 and not args.no_side_records:
             # BASELINE configs[2], [3] on the same box, same agent count and replay size (extra keys; `value` is DDPG)
-            side_U = max(1, U // 4)
+            # the same launch length as the headline: U x steps = 6,400 timed updates per agent by default
             for algo in ("sac", "naf", "kl"):
-                out[algo] = side_record(algo, NA, side_U if algo != "kl" else max(1, U // 8), args.steps, args.warmup,
-                                        torch, local_rank)
+                out[algo] = side_record(algo, NA, U, args.steps, args.warmup, torch, local_rank)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -17,7 +17,8 @@ same schedule, same pickle, Philox random streams instead of numpy's.
 
 Under ``python -m torch.distributed.run --nproc-per-node N main.py ...`` the INDEX range is dealt round-robin to
 the N ranks (one GPU each, nothing exchanged while training); one all-gather of the run records at the end
-(RCCL on GPUs, rlcontrol_amd/sweep.py) and rank 0 writes the single pickle.
+(RCCL on GPUs, rlcontrol_amd/sweep.py) and rank 0 writes the single pickle; until then every rank keeps a
+reference-schema pickle of its own shard up to date (``data_<..>.rank<r>of<N>.pkl``, re-written after every index).
 """
 import argparse
 import json
@@ -264,7 +265,10 @@ def main(argv=None):
     save_dir = args.save_dir + "/" + env_name + "_" + agent_name + 'results/'
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # RLC_FORCE_DIST=1 takes the multi-process path at world size 1 too (one rank under torch.distributed.run): the
+    # barrier, the MAX all-reduce and the all-gather then really go through RCCL -- the one-GPU rehearsal of the
+    # 8-GPU INDEX sweep (tests/test_gpu_rccl.py)
+    if world > 1 or (os.environ.get("RLC_FORCE_DIST", "0") == "1" and "RANK" in os.environ):
         return main_distributed(args, agent_json, env_json, train_env, test_env, env_params, arg_params, save_dir)
 
     if args.device_rollout:
@@ -298,6 +302,8 @@ def main_distributed(args, agent_json, env_json, train_env, test_env, env_params
         device = torch.device("cuda", args.gpu)
     if not dist.is_initialized():
         dist.init_process_group("nccl" if on_gpu else "gloo", **({"device_id": device} if on_gpu else {}))
+    if os.environ.get("RLC_LOG_COLLECTIVES", "0") == "1" and rank == 0:
+        print("main_distributed: backend=%s world=%d" % (dist.get_backend(), world), flush=True)
     mine = sweep.rank_indices(args.indices[0], args.indices[1], args.indices[2], rank, world)
     local = new_data_dict(agent_json, env_json)
     verbose = (not args.quiet) and rank == 0
@@ -306,13 +312,27 @@ def main_distributed(args, agent_json, env_json, train_env, test_env, env_params
     interval = int(env_json["EvalIntervalMilSteps"] * 1000000)
     eval_shape = (total // interval + 1, int(env_json["EvalEpisodes"]))
     runs, failure = {}, None
+    # Every rank re-writes a reference-schema pickle of ITS shard after each index it completes, as the reference
+    # re-pickles after every index (main.py:205-209): a rank that dies late loses nothing that finished, and the shard
+    # files merge offline exactly as the reference merges its per-process pickles (main_concurrent.py:107-154
+    # combine_data_dictionaries).  Rank 0 removes them once the one merged pickle is on disk.
+    shard_file = save_dir + "data_%d_%d_%d.rank%dof%d.pkl" % (tuple(args.indices) + (rank, world))
+
+    def write_shard():
+        os.makedirs(save_dir, exist_ok=True)
+        with open(shard_file + ".tmp", "wb") as out_file:
+            pickle.dump(local, out_file)
+        os.replace(shard_file + ".tmp", shard_file)
+
     try:
         if args.device_rollout:
             if mine:
                 run_indices_on_device(mine, agent_json, env_json, env_params, arg_params, local, verbose=verbose)
+                write_shard()          # the device loop finishes all of the rank's indices together
         else:
             for index in mine:
                 run_index(index, agent_json, env_json, train_env, test_env, env_params, arg_params, local, verbose=verbose)
+                write_shard()
         # local runs in index order (each setting's list is in increasing index = increasing seed)
         for sweep_id, sd in local["experiment_data"].items():
             for rd in sd["runs"]:
@@ -359,6 +379,8 @@ def main_distributed(args, agent_json, env_json, train_env, test_env, env_params
         with open(save_dir + "data_%d_%d_%d.pkl" % tuple(args.indices), "wb") as out_file:
             pickle.dump(data, out_file)
     dist.barrier()
+    if os.path.exists(shard_file):       # the merged pickle holds everything the shard files held
+        os.remove(shard_file)
     return data
 
 

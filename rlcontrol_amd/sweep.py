@@ -93,7 +93,7 @@ def all_reduce_max(value, device=None):
     """max of an integer over the ranks (sizes the exchange record)"""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):       # a group of ONE rank still runs the collective
         return int(value)
     t = torch.tensor([int(value)], dtype=torch.int64)
     if device is not None:
@@ -112,7 +112,7 @@ def all_gather_runs(local_vectors, runs_per_rank, vec_len, device=None):
         buf[i] = torch.from_numpy(np.asarray(v, np.float64))
     if device is not None:
         buf = buf.to(device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return buf.cpu().numpy()
     out = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
     dist.all_gather(out, buf)

@@ -117,6 +117,8 @@ def test_main_under_two_ranks_writes_one_complete_pickle(tmp_path):
         assert p.exitcode == 0
     with open(tmp_path / "res" / "Pendulum-v0_ddpgresults" / "data_0_7_70.pkl", "rb") as f:
         multi = pickle.load(f)
+    # the per-rank shard pickles (re-written after every index) are gone once the merged pickle exists
+    assert sorted(os.listdir(tmp_path / "res" / "Pendulum-v0_ddpgresults")) == ["data_0_7_70.pkl"]
     # the same sweep in one process
     sys.path.insert(0, ROOT)
     import json
@@ -251,4 +253,50 @@ def test_failing_rank_ends_the_sweep_on_every_rank_promptly(tmp_path):
         assert p.exitcode == 3                      # both ranks raised -- nobody hangs in the all-gather
     assert "this rank failed" in (tmp_path / "err1.txt").read_text()
     assert "another rank failed" in (tmp_path / "err0.txt").read_text()
-    assert not (tmp_path / "res" / "Pendulum-v0_ddpgresults" / "data_0_7_28.pkl").exists()
+    resdir = tmp_path / "res" / "Pendulum-v0_ddpgresults"
+    assert not (resdir / "data_0_7_28.pkl").exists()
+    # ... but what the healthy rank finished is on disk in the reference's schema (main.py:205-209 re-pickles after every
+    # index), ready for the reference's offline merge (main_concurrent.py:107-154)
+    import pickle
+    with open(resdir / "data_0_7_28.rank0of2.pkl", "rb") as f:
+        shard = pickle.load(f)
+    seeds = sorted((sid, r["random_seed"]) for sid, sd in shard["experiment_data"].items() for r in sd["runs"])
+    assert seeds == [(0, 0), (14, 0)]               # indices 0 and 14 of range(0, 28, 7) are rank 0's
+    assert shard["experiment"]["agent"]["agent_name"] == "DDPG"
+    assert not (resdir / "data_0_7_28.rank1of2.pkl").exists()      # rank 1 failed on its first index
+
+
+def _main_worker_forced(port, tmp):
+    sys.path.insert(0, ROOT)
+    import json
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      RLC_FORCE_DIST="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    import main as drv
+    drv.create_agent = lambda name, cfg: _FakeAgent(cfg)
+    envf = os.path.join(tmp, "Pendulum-v0.json")
+    with open(envf, "w") as f:
+        json.dump(ENV2, f)
+    calls = []
+    orig_gather, orig_reduce = dist.all_gather, dist.all_reduce
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), orig_gather(*a, **k))[1]
+    dist.all_reduce = lambda *a, **k: (calls.append("all_reduce"), orig_reduce(*a, **k))[1]
+    drv.main(["--env_json", envf, "--agent_json", os.path.join(ROOT, "jsonfiles/agent/ddpg.json"),
+              "--indices", "0", "7", "21", "--save_dir", os.path.join(tmp, "res"), "--quiet"])
+    with open(os.path.join(tmp, "calls.json"), "w") as f:
+        json.dump(calls, f)
+
+
+def test_forced_dist_at_world_size_one_runs_the_collectives(tmp_path):
+    """RLC_FORCE_DIST=1 (the one-GPU RCCL rehearsal, tests/test_gpu_rccl.py) under gloo: one rank, real collectives"""
+    import json
+    import pickle
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_main_worker_forced, args=(37500 + (os.getpid() % 2000), str(tmp_path)))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0
+    calls = json.load(open(tmp_path / "calls.json"))
+    assert calls.count("all_gather") == 1 and calls.count("all_reduce") >= 2
+    with open(tmp_path / "res" / "Pendulum-v0_ddpgresults" / "data_0_7_21.pkl", "rb") as f:
+        data = pickle.load(f)
+    assert sorted(data["experiment_data"]) == [0, 7, 14]
