@@ -140,13 +140,14 @@ def cpu_baseline(seconds=15.0, records=REPLAY_N, all_cores=True):
     return out
 
 
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic(n_agents, updates_per_launch, kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, scripts/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for 16 B/lane streams -> an upper bound, the dword-load share being uncalibrated).  Counters cannot be read
+    WRITE_SIZE in separate runs, scripts/pmc_summary.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes --
+    profiles/r03_peaks.json calibrates the factor 2 for the k-loop's dword stream as well, so this is the figure, not
+    an upper bound).  Counters cannot be read
     inside a timed run, so this is the measurement of the same command line taken when the kernel last changed
     (scaled per update when the launch length differs); returns (bytes per launch | None, source file | None)."""
     for name in PMC_FILES:
@@ -212,14 +213,34 @@ def aggregate_value(world, agents, updates_per_step, steps, dt_max):
     return world * agents * updates_per_step * steps / dt_max
 
 
+def measured_peaks():
+    """roofs measured on a box of this pool by scripts/micro/peaks.hip (profiles/r03_peaks.json): quoted beside the spec
+    peaks the fractions are priced against; None when the file is absent"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_peaks.json")) as f:
+            m = json.load(f)
+        return {"fp32_matrix_tflops": m["mfma_f32_16x16x4_tflops"], "hbm_read_gbs": m["read_f4_gbs"],
+                "hbm_copy_gbs": m["copy_f4_gbs"], "source": "profiles/r03_peaks.json"}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def roofline_record(flop_per_update, bytes_per_update, updates_per_launch, launch_s):
     ach_flops = flop_per_update * updates_per_launch / launch_s
     ach_bytes = bytes_per_update * updates_per_launch / launch_s
-    return ({"bound": "mfma", "achieved": ach_flops / 1e12, "peak": PEAK_FP32_MATRIX / 1e12, "unit": "TFLOP/s",
-             "frac": ach_flops / PEAK_FP32_MATRIX, "kernel_ms_per_launch": launch_s * 1e3,
-             "flop_per_update": flop_per_update},
-            {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-             "frac": ach_bytes / PEAK_HBM, "bytes_per_update": bytes_per_update})
+    roof = {"bound": "mfma", "achieved": ach_flops / 1e12, "peak": PEAK_FP32_MATRIX / 1e12, "unit": "TFLOP/s",
+            "frac": ach_flops / PEAK_FP32_MATRIX, "kernel_ms_per_launch": launch_s * 1e3,
+            "flop_per_update": flop_per_update}
+    hbm = {"bound": "hbm", "achieved": ach_bytes / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+           "frac": ach_bytes / PEAK_HBM, "bytes_per_update": bytes_per_update}
+    mp = measured_peaks()
+    if mp:
+        roof["peak_measured"] = mp["fp32_matrix_tflops"]
+        roof["frac_of_measured"] = ach_flops / 1e12 / mp["fp32_matrix_tflops"]
+        hbm["peak_measured"] = mp["hbm_read_gbs"]
+        hbm["frac_of_measured"] = ach_bytes / 1e9 / mp["hbm_read_gbs"]
+        roof["peak_measured_source"] = hbm["peak_measured_source"] = mp["source"]
+    return roof, hbm
 
 
 def _fill_from_host(pop, host, torch):
@@ -296,6 +317,8 @@ def main():
                          "MAX all-reduce and all-gather then go through RCCL -- the one-GPU rehearsal of --gpus 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="skip the SAC / NAF sub-records")
+    ap.add_argument("--side-only", default="", choices=["", "sac", "naf", "kl"],
+                    help="profiling helper: run ONLY that sub-record (no DDPG headline) and print its JSON")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-records", type=int, default=REPLAY_N)
     ap.add_argument("--cpu-worker", action="store_true", help="internal: one process of the all-cores CPU baseline")
@@ -336,6 +359,10 @@ def main():
         entry.build()
     if dist is not None:
         dist.barrier()
+    if args.side_only:
+        print(json.dumps(side_record(args.side_only, args.agents, args.updates_per_step, args.steps, args.warmup, torch,
+                                     local_rank)))
+        return
     from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
 
     NA, U = args.agents, args.updates_per_step

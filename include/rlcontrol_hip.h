@@ -119,6 +119,14 @@ int rlc_replay_sample_indices(rlc_handle* h, int32_t agent, int32_t k, int64_t* 
  *    (agents/DDPG.py:36, hydra_ddpg_network.py:162-171).  states [n][S] for agents first..first+n-1,
  *    out [n][A] = tanh(.)*action_max, fp32 like the Session.run fetch. */
 int rlc_ddpg_act(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions);
+/* The same forward, split in two for the step loop of experiment.py:132-135 -- `agent.update(obs, obs_n, ...)` then
+ * `agent.step(obs_n)`: BaseAgent.update already holds next_state (agents/base_agent.py:54-63), so the forward for it is
+ * QUEUED behind the update just launched (no host synchronisation) and step() FETCHES the action -- one launch
+ * sequence and one synchronisation per environment step.  fetch fails unless the same agent range is queued; anything
+ * that changes the weights between the two calls (another update, set_blob) makes the queued result stale: the
+ * Python agent then drops it and calls rlc_ddpg_act. */
+int rlc_ddpg_act_queue(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states);
+int rlc_ddpg_act_fetch(rlc_ddpg* h, int32_t first_agent, int32_t n, float* out_actions);
 /* same + device OU noise and clip (utils/exploration_policy.py:18-21); reset -> noise = mu (:23-24) */
 int rlc_ddpg_act_explore(rlc_ddpg* h, int32_t first_agent, int32_t n, const double* states, float* out_actions);
 int rlc_ddpg_reset_noise(rlc_ddpg* h, int32_t first_agent, int32_t n);
@@ -144,6 +152,12 @@ int rlc_ddpg_get_kernel(const rlc_ddpg* h, int32_t* variant_in_use);
  * occupy the GPU while an update runs: the workgroups of an agent meet at four barriers per update).  Results equal the
  * one-workgroup kernel up to the summation order over the batch. */
 int rlc_ddpg_set_split(rlc_ddpg* h, int32_t n_workgroups);
+/* Failure behaviour of latency mode (DDPG and KL): when a cross-workgroup barrier does not complete (a peer workgroup
+ * was not resident: the GPU is shared), every workgroup of the launch leaves at that barrier before any store of the
+ * phase behind it, the update call fails, and the handle refuses further latency-mode updates until set_split is called
+ * again (parameters / optimizer state are those of the last completed phase of the failed update: reload them first).
+ * Test hook: the next latency-mode launch of `h` behaves as if its first barrier had failed. */
+int rlc_debug_fail_next_split(rlc_handle* h);
 
 /* -- debug taps of the LAST update of one agent (the 1e-5 checks): which: 0 q before the critic step
  *    (train_critic's fetch, hydra_ddpg_network.py:155), 1 TD target y, 2 scaled actor output (DDPG.py:90),

@@ -21,9 +21,9 @@ EXPORTS = (
     "rlc_ddpg_init_target",
     "rlc_replay_add", "rlc_replay_add_batch", "rlc_replay_fill_all_dev", "rlc_replay_size",
     "rlc_replay_gather", "rlc_replay_sample_indices",
-    "rlc_ddpg_act", "rlc_ddpg_act_explore", "rlc_ddpg_reset_noise", "rlc_ddpg_qval",
+    "rlc_ddpg_act", "rlc_ddpg_act_queue", "rlc_ddpg_act_fetch", "rlc_ddpg_act_explore", "rlc_ddpg_reset_noise", "rlc_ddpg_qval",
     "rlc_ddpg_update", "rlc_ddpg_update_batch", "rlc_ddpg_set_kernel", "rlc_ddpg_get_kernel", "rlc_ddpg_set_split",
-    "rlc_ddpg_last_tap", "rlc_ddpg_enable_grad_taps",
+    "rlc_ddpg_last_tap", "rlc_ddpg_enable_grad_taps", "rlc_debug_fail_next_split",
     "rlc_timer_begin", "rlc_timer_end",
     "rlc_sac_create", "rlc_sac_param_count", "rlc_sac_set_blob", "rlc_sac_get_blob", "rlc_sac_set_beta_powers",
     "rlc_sac_get_beta_powers", "rlc_sac_init_target", "rlc_sac_act", "rlc_sac_update", "rlc_sac_update_batch",

@@ -52,12 +52,17 @@ class BaseAgent(object):
             self.replay_buffer.add(state, action, reward, next_state, self._transition_gamma(is_terminal))
         if self.norm_type != 'none':
             self.network_manager.input_norm.update(np.array([state]))
-        self.learn()
+        # Experiment asks step(next_state) next unless the episode ended here (experiment.py:127-135)
+        self.learn(None if (is_terminal or is_truncated) else next_state)
 
-    def learn(self):
+    def learn(self, next_state=None):
         ready = self.replay_buffer.get_size() > max(self.warmup_steps, self.batch_size)
         if ready:
-            self.network_manager.update_from_replay(self.replay_buffer.sample_indices(self.batch_size))
+            indices = self.replay_buffer.sample_indices(self.batch_size)
+            if next_state is not None and getattr(self.network_manager, "queues_next_action", False):
+                self.network_manager.update_from_replay(indices, next_state=next_state)
+            else:
+                self.network_manager.update_from_replay(indices)
 
     def reset(self):
         self.network_manager.reset()

@@ -60,6 +60,97 @@ def _units():
     return units
 
 
+_LLVM = "/opt/rocm/lib/llvm/bin"
+# Units whose kernels must not carry whole-wave spills (see audit_object); the MFMA kernels are reported, not refused:
+# their SGPR spills sit at phase boundaries and they run two waves per SIMD with the full 256-register budget.
+GUARDED_UNITS = ("ddpg_generic.o", "sac_generic.o", "naf_generic.o", "kl_generic.o")
+USAGE_JSON = os.path.join(_HERE, "kernel_resource_usage.json")
+
+
+def audit_object(obj):
+    """Per-kernel register / spill report of one compiled unit, read back from the gfx950 code object inside `obj`:
+    vgpr_count, sgpr_spill_count, vgpr_spill_count, scratch bytes (the code object's metadata = what
+    -Rpass-analysis=kernel-resource-usage prints), `wwm_spills`: the number of whole-wave scratch stores / loads
+    (`s_or_saveexec_b64 s[..], -1` + `scratch_store/load`), i.e. VGPRs that hold spilled SGPRs in their lanes and are
+    themselves spilled to scratch, and `exec0_copies`: register-allocator split copies placed in front of the exec
+    restore of a block that a divergent loop leaves with exec == 0.  The second is what hipcc 7.2 did to naf_generic.hip
+    in round 2 (a 64-bit index kept a stale high word -> HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION), the first is the
+    register-pressure regime it happened in (profiles/r03_naf_spill_fault.md).  Nothing in the source shows either: the
+    build has to watch them."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        fb, co = os.path.join(tmp, "x.hipfb"), os.path.join(tmp, "x.co")
+        if subprocess.call([os.path.join(_LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, obj],
+                           stderr=subprocess.DEVNULL) != 0:
+            return {}                     # a host-only unit: no device code in it
+        subprocess.check_call([os.path.join(_LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output([os.path.join(_LLVM, "llvm-readelf"), "--notes", co], text=True)
+        dis = subprocess.check_output([os.path.join(_LLVM, "llvm-objdump"), "-d", "--symbolize-operands",
+                                       "--no-show-raw-insn", co], text=True)
+    kernels, cur = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*\.name:\s+(\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.match(r"\s*\.(private_segment_fixed_size|sgpr_spill_count|vgpr_spill_count|vgpr_count|sgpr_count|"
+                     r"group_segment_fixed_size):\s+(\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = int(m.group(2))
+    lines = dis.splitlines()
+    execz_targets = set(m.group(1) for m in (re.search(r"s_cbranch_execz\s+(L\d+)", l) for l in lines) if m)
+    cur_k, prev_saveexec = None, False
+    for i, line in enumerate(lines):
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m and not re.match(r"L\d+$", m.group(1)):
+            cur_k = m.group(1) if m.group(1) in kernels else None
+            prev_saveexec = False
+            continue
+        if cur_k is None:
+            continue
+        if m:
+            # a local label: if an s_cbranch_execz lands here (exec == 0 on that edge), are there VGPR moves in front of
+            # the block's `s_or_b64 exec, exec, ...`?  (the round-2 NAF miscompile: profiles/r03_naf_spill_fault.md)
+            if m.group(1) in execz_targets:
+                moves, j = 0, i + 1
+                while j < len(lines):
+                    ins = lines[j].strip().split("//")[0].strip()
+                    if re.match(r"v_mov_b(32|64)|v_accvgpr", ins):
+                        moves += 1
+                    elif re.match(r"s_or_b64 exec, exec,", ins):
+                        if moves:
+                            kernels[cur_k]["exec0_copies"] = kernels[cur_k].get("exec0_copies", 0) + 1
+                        break
+                    elif not re.match(r"s_(waitcnt|nop|mov_b32|mov_b64 s)", ins):
+                        break                     # anything else: an ordinary block, not a bare restore-then-reconverge
+                    j += 1
+            continue
+        ins = line.strip()
+        if prev_saveexec and ins.startswith("scratch_"):
+            kernels[cur_k]["wwm_spills"] = kernels[cur_k].get("wwm_spills", 0) + 1
+        prev_saveexec = bool(re.match(r"s_or_saveexec_b64 s\[\d+:\d+\], -1", ins))
+    for k in kernels.values():
+        k.setdefault("wwm_spills", 0)
+        k.setdefault("exec0_copies", 0)
+    return kernels
+
+
+def check_spill_policy(usage):
+    """usage: {unit basename: audit_object(...)}.  Refuse whole-wave spills and exec-0 restore copies in the guarded
+    units."""
+    bad = ["%s: %s (%d whole-wave spill ops, %d exec-0 restore copies; %d SGPR + %d VGPR spills)" % (
+               u, k, r["wwm_spills"], r.get("exec0_copies", 0), r.get("sgpr_spill_count", 0), r.get("vgpr_spill_count", 0))
+           for u, ks in sorted(usage.items()) if u in GUARDED_UNITS for k, r in sorted(ks.items())
+           if r["wwm_spills"] > 0 or r.get("exec0_copies", 0) > 0]
+    if bad and os.environ.get("RLC_ALLOW_WWM_SPILLS", "0") != "1":
+        raise RuntimeError("kernels that spill SGPR-spill VGPRs to scratch (the combination hipcc 7.2 miscompiled, "
+                           "DESIGN.md 5.5) -- reduce their register pressure or set RLC_ALLOW_WWM_SPILLS=1 to look at "
+                           "them anyway:\n  " + "\n  ".join(bad))
+    return bad
+
+
 def _stale(src, obj, hdr_time):
     return (not os.path.exists(obj)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
 
@@ -89,19 +180,34 @@ def build(force=False, verbose=False, jobs=None):
     todo = [u for u in _units() if force or _stale(u[0], u[1], hdr_time)]
 
     def compile_one(u):
+        import json
         src, obj, defs = u
         cmd = [_hipcc()] + CFLAGS + defs + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(obj + ".usage.json", "w") as f:
+            json.dump(audit_object(obj), f)
 
     if todo:
         with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
             list(ex.map(compile_one, todo))
+    import json
+    usage = {}
+    for _, obj, _ in _units():
+        if not os.path.exists(obj + ".usage.json"):          # an object of an older build
+            with open(obj + ".usage.json", "w") as f:
+                json.dump(audit_object(obj), f)
+        with open(obj + ".usage.json") as f:
+            usage[os.path.basename(obj)] = json.load(f)
+    check_spill_policy(usage)                                # before the link: a refused build leaves no library
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + [u[1] for u in _units()]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if not STAMPS and not FAST:
+        with open(USAGE_JSON, "w") as f:
+            json.dump(usage, f, indent=1, sort_keys=True)
     with open(VARIANT_TAG, "w") as f:
         f.write(VARIANT)
     return OUT

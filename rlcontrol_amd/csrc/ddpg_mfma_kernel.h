@@ -113,6 +113,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     if (tid < 16) L.hbuf[MB * u.LDH + tid] = 0.0f;
     __syncthreads();
 
+    stagger_start();
+#ifdef RLC_PRIO_YOUNG
+    if (u.wave >= 4) __builtin_amdgcn_s_setprio(1);     // the second-dispatched half loses every issue arbitration otherwise
+#endif
     f32x4 acc[MT][NTW];
 #ifdef RLC_STAMPS
     // diagnostic build only: phase boundaries in shader cycles, written where the critic gradient tap lives
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             if (!rlc_train_step_device(rollout, agent, (float*)L.hbuf, upd == 0 ? q8_first : 0)) continue;
         }
         // ================= sample + gather (utils/replaybuffer.py:32-37) =================
+        if (!(ablate(4) && upd > 0)) {
         u.sub_begin();
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
@@ -176,6 +181,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
         }
         u.sub_stamp(27);
+        }
         __syncthreads();
         STAMP();
 

@@ -32,24 +32,38 @@ struct RlcSplit {
 };
 
 // barrier over the C workgroups of one agent (see the header comment); `gen` counts this workgroup's barriers
-__device__ __forceinline__ void split_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err) {
+// Returns false -- for EVERY thread of the workgroup -- when the barrier did not complete (a poll timed out here or in
+// another workgroup of the launch: the error word is set).  The caller returns at once: no Adam / Polyak store of a
+// phase whose inputs are incomplete is ever issued, so parameters and optimizer state stay those of the last
+// completed phase; the host reports the failure and poisons the handle (rlc_api.hip launch_update).
+__device__ __forceinline__ bool split_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
+    __shared__ int failed;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int target = gen * (unsigned int)C;
-        int spins = 0;
+        int spins = 0, bad = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) { atomicExch(err, 1); break; }      // ~seconds: a peer is not resident
+            // ~seconds: a peer is not resident -- or a peer has already given up and left (its error word is set)
+            if (++spins > (1 << 22) || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                atomicExch(err, 1);
+                bad = 1;
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // a workgroup that passed the poll still stops when another one of the launch has failed: nobody may go on
+        // to reduce partials (or read an image) its peers have not finished
+        failed = bad | __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    return failed == 0;
 }
 
 // g[p] = sum_cc part[cc][p] for the float4 groups of [lo, hi) dealt to workgroup c; Adam on (th, m, v) with alpha;
@@ -250,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_split_kernel(RlcDev 
         u.template trunk_grad_adam<NoExtra, true>(acc, nullptr, nullptr, nullptr, 0.0f, d.oW1, d.ob1, mine, nullptr, 0.0f, L.x);
         u.template wgrad_adam<1, AD, -2, true>(L.dq, L.a, HC, nullptr, nullptr, nullptr, 0.0f, mine + d.oWc2, nullptr, 0.0f,
                                                L.wvec);
-        split_barrier(ctr, C, gen, sp.err);
+        if (!split_barrier(ctr, C, gen, sp.err)) return;
         // ---- reduce + critic Adam on my slice: trunk [0, oWa2) without target update, critic block with it ----
         {
             const float alpha_c = adam_alpha(lr_c, pw2, pw3);
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_split_kernel(RlcDev 
                                  d.Pdev, tap_gc);
             pw2 *= 0.9f; pw3 *= 0.999f;
         }
-        split_barrier(ctr, C, gen, sp.err);
+        if (!split_barrier(ctr, C, gen, sp.err)) return;
 
         // ================= step 4: actor forward with the updated trunk =================
         u.trunk(th + d.oW1, th + d.ob1, L.x);
@@ -356,13 +370,13 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_split_kernel(RlcDev 
         u.template trunk_grad_adam<NoExtra, true>(acc, nullptr, nullptr, nullptr, 0.0f, d.oW1, d.ob1, mine, nullptr, 0.0f, L.x);
         u.template wgrad_adam<AD, 0, -2, true>(L.dz, nullptr, HA, nullptr, nullptr, nullptr, 0.0f, mine + d.oWa2, nullptr, 0.0f,
                                                L.wvec);
-        split_barrier(ctr, C, gen, sp.err);
+        if (!split_barrier(ctr, C, gen, sp.err)) return;
         {
             const float alpha_a = adam_alpha(lr_a, pw0, pw1);
             split_reduce_adam<U>(parts, pstride, C, c, 0, d.ocritic0, th, m_a, v_a, alpha_a, tt, tau, 0, d.ocritic0, tap_ga);
             pw0 *= 0.9f; pw1 *= 0.999f;
         }
-        split_barrier(ctr, C, gen, sp.err);
+        if (!split_barrier(ctr, C, gen, sp.err)) return;
     }
     if (c == 0 && tid == 0) {
         pw[0] = pw0; pw[1] = pw1; pw[2] = pw2; pw[3] = pw3;

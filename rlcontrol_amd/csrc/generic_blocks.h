@@ -6,10 +6,13 @@
 
 namespace gen {
 
-// workgroup size of the any-shape kernels; a translation unit may lower it before including this header (each .hip
-// is compiled and linked on its own, so the device code of two units never mixes)
+// workgroup size of the any-shape kernels; a translation unit may change it before including this header (each .hip
+// is compiled and linked on its own, so the device code of two units never mixes).  512 threads = two waves per SIMD =
+// 256 registers per lane: at 1024 threads (128 registers) the four update kernels spilled 90-190 VGPRs beside 290-590
+// SGPR spills, the regime in which hipcc 7.2 miscompiled naf_generic.hip (profiles/r03_naf_spill_fault.md); at 512
+// rlcontrol_amd/build.py's audit reports no whole-wave spill and no exec-0 restore copy in any of them.
 #ifndef RLC_GEN_THREADS
-#define RLC_GEN_THREADS 1024
+#define RLC_GEN_THREADS 512
 #endif
 constexpr int kThreads = RLC_GEN_THREADS;
 constexpr int kRows = 4;   // batch rows per thread-item in the dense loops

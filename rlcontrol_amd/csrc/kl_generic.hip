@@ -390,7 +390,10 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv_ar
         if (tid == 0) dv.kl_step[agent] = step;
         // ---- update_target_network: the V network only, target*(1-tau) + param*tau ----
         KL_PHASE();
-        for (int p = d.vW1 + tid; p < d.Pdev; p += kThreads) tt[p] = tt[p] * (1.0f - dv.tau) + th[p] * dv.tau;
+        // target_param * (1 - tau) + param * tau as torch evaluates it (reversekl_network.py:222-225): two separately
+        // rounded products and one sum -- no fused multiply-add
+        for (int p = d.vW1 + tid; p < d.Pdev; p += kThreads)
+            tt[p] = __fadd_rn(__fmul_rn(tt[p], 1.0f - dv.tau), __fmul_rn(th[p], dv.tau));
         __syncthreads();
     }
 #undef KL_PHASE

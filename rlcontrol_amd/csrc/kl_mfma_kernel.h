@@ -49,24 +49,38 @@ struct KlSplit {
     int C, n_agents;
 };
 
-__device__ __forceinline__ void kl_group_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err) {
+// Returns false -- for EVERY thread of the workgroup -- when the barrier did not complete (a poll timed out here or in
+// another workgroup of the launch: the error word is set).  The caller returns at once: no Adam / Polyak store of a
+// phase whose inputs are incomplete is ever issued, so parameters and optimizer state stay those of the last
+// completed phase; the host reports the failure and poisons the handle (rlc_api.hip launch_update).
+__device__ __forceinline__ bool kl_group_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
+    __shared__ int failed;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned int target = gen * (unsigned int)C;
-        int spins = 0;
+        int spins = 0, bad = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1 << 22)) { atomicExch(err, 1); break; }      // ~seconds: a peer is not resident
+            // ~seconds: a peer is not resident -- or a peer has already given up and left (its error word is set)
+            if (++spins > (1 << 22) || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                atomicExch(err, 1);
+                bad = 1;
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // a workgroup that passed the poll still stops when another one of the launch has failed: nobody may go on
+        // to reduce partials (or read an image) its peers have not finished
+        failed = bad | __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    return failed == 0;
 }
 
 struct KSmem {
@@ -248,13 +262,13 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
             // helper: per update, the owner's z1s image and the current Q weights -> my passes
             float* zb = sp.zbuf + (size_t)rel_agent * MB * LDH;
             for (int upd = 0; upd < n_updates; upd++) {
-                kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);
+                if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return;
                 for (int i = tid; i < (MB * LDH) >> 2; i += kThreads)
                     reinterpret_cast<lds_f32x4*>(L.z1s)[i] = reinterpret_cast<const f32x4*>(zb)[i];
                 for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;
                 __syncthreads();
                 node_passes();
-                kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);
+                if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return;
             }
             return;
         }
@@ -445,9 +459,9 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
             }
             for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;
             __syncthreads();
-            if constexpr (SPLIT) kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);     // z1s published
+            if constexpr (SPLIT) { if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return; }     // z1s published
             node_passes();
-            if constexpr (SPLIT) kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err);     // every pass has landed
+            if constexpr (SPLIT) { if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return; }     // every pass has landed
             __syncthreads();
             // ================= 7: one wave per state: log pi at the nodes, d loss / d lp, seeds of mean and log_std =================
             for (int b = u.wave; b < B; b += kWaves) {

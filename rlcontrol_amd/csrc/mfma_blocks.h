@@ -44,6 +44,33 @@ typedef RLC_LDS int lds_i32;
 typedef RLC_LDS double lds_f64;
 typedef RLC_LDS long long lds_i64;
 
+// Timing-only ablations for diagnostic builds (scripts/ab_ablate.sh; results are wrong by construction, the product
+// build has RLC_ABLATE == 0): bit 0 no weight-gradient GEMM at all, 1 its k-loops only (no prefetch / Adam epilogue),
+// 2 no action-row loop, 3 no first-layer pass, 4 sample + gather only in the first update of a launch, 5 no backward
+// k-loops, 6 no forward k-loops, 7 no first-layer gradient, 8 no row_dot, 9 no mask stores, 10 no bias_relu,
+// 11 weight-gradient epilogue without its stores, 12 without its W / m / v / W' loads, 13 without the Adam arithmetic
+#ifndef RLC_ABLATE
+#define RLC_ABLATE 0
+#endif
+constexpr bool ablate(int bit) { return ((RLC_ABLATE) >> bit) & 1; }
+
+// Experiment switch (diagnostic builds): workgroup i of a launch starts (i mod RLC_STAGGER_WAYS) * RLC_STAGGER_US /
+// RLC_STAGGER_WAYS microseconds late, so that the memory-bound phases of the agents do not coincide chip-wide
+#ifndef RLC_STAGGER_US
+#define RLC_STAGGER_US 0
+#endif
+#ifndef RLC_STAGGER_WAYS
+#define RLC_STAGGER_WAYS 4
+#endif
+__device__ __forceinline__ void stagger_start() {
+    if constexpr (RLC_STAGGER_US > 0) {
+        const long long wait = (long long)(blockIdx.x % RLC_STAGGER_WAYS) * RLC_STAGGER_US * 100 / RLC_STAGGER_WAYS;   // 100 MHz ticks
+        const long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        __syncthreads();
+    }
+}
+
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;     // two waves per SIMD: one can issue MFMA while the other does VALU / waits on loads
 constexpr int SMAX = 8;       // state rows are padded to 8 floats in LDS (two ds_read_b128)
@@ -51,6 +78,23 @@ constexpr int SMAX = 8;       // state rows are padded to 8 floats in LDS (two d
 // Row stride (bytes) of the byte masks for NT16 N tiles: 4*odd dwords, so that the dword a lane reads in the
 // backward GEMM (row 16mt+c, bytes nc+4g..+3) sits in bank (4*odd*c + g + const) mod 64: conflict-free for all lanes.
 constexpr int mask_stride(int nt16) { return ((nt16 + 1) & 1) ? 16 * (nt16 + 1) : 16 * (nt16 + 2); }
+
+// Adam's m / v slots are touched once per update: with RLC_NT_STATE they are loaded / stored non-temporally (the `nt`
+// bit), so that they do not displace the weight matrices the GEMMs re-read from L2 / the Infinity Cache
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+#ifdef RLC_NT_STATE
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void st_stream(float* p, f32x4 v) {
+#ifdef RLC_NT_STATE
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -168,6 +212,7 @@ struct Blk {
     // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
     // ---------------------------------------------------------------------------------------
     __device__ __forceinline__ void trunk(const float* W1, const float* b1, const lds_f32* xs) {
+        if constexpr (ablate(3)) return;
         if (S <= 4) trunk_t<4>(W1, b1, xs);      // wave-uniform: Pendulum-sized states need one 16-byte read per row
         else trunk_t<SMAX>(W1, b1, xs);
     }
@@ -371,6 +416,7 @@ struct Blk {
 #ifdef RLC_STAMPS
         const long long t_w0 = clock64();
 #endif
+        if constexpr (ablate(6)) return;
         const int nown = nown_of(NT);              // tiles this wave owns: wave-uniform
         const bool tail8 = (K & 15) == 8 && K > 16;
         const int KB = tail8 ? K >> 4 : (K + 15) >> 4;
@@ -397,6 +443,7 @@ struct Blk {
     __device__ __forceinline__ void bias_relu(f32x4 (&acc)[MT][NTW], const float* bias, int N, const lds_f32* E = nullptr,
                                               const float* Wx = nullptr /* tile-blocked matrix whose rows xrow0+j multiply E */,
                                               int xrow0 = 0) {
+        if constexpr (ablate(10)) return;
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
@@ -426,6 +473,7 @@ struct Blk {
     // cf is only evaluated for valid columns.
     template <bool STEP, int NJ, class CF>
     __device__ __forceinline__ void row_dot(const f32x4 (&acc)[MT][NTW], int N, CF cf, lds_f32* part) {
+        if constexpr (ablate(8)) return;
         const int NT = (N + 15) >> 4;
         float co[NTW][NJ];
 #pragma unroll
@@ -522,6 +570,7 @@ struct Blk {
     // fp8 e4m3, which the backward GEMM turns into floats two at a time (v_cvt_pk_f32_fp8).
     template <int BIT, bool OVERWRITE>
     __device__ __forceinline__ void store_masks(const f32x4 (&acc)[MT][NTW], int N) {
+        if constexpr (ablate(9)) return;
         const int NT = (N + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
@@ -761,6 +810,7 @@ struct Blk {
 #pragma unroll
                 for (int i = 0; i < NTW; i++) acc[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (ablate(5)) return;
         const int nown = nown_of(NT);
         const int NTblk = (Nk + 15) >> 4;          // blocks per row of the tile-blocked W
         const bool tail8 = (Nk & 15) == 8 && Nk > 16;
@@ -796,6 +846,7 @@ struct Blk {
     __device__ __forceinline__ void trunk_grad_adam(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
                                                     float alpha, int oW1, int ob1, float* tap, float* tt, float tau,
                                                     const lds_f32* xs, EXTRA extra = EXTRA{}) {
+        if constexpr (ablate(7)) return;
         if (S <= 4) trunk_grad_adam_t<4, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);     // wave-uniform
         else trunk_grad_adam_t<SMAX, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);
     }
@@ -883,6 +934,7 @@ struct Blk {
                                                int N, float* Wp, float* mp, float* vp,
                                                float alpha, float* tapp, float* Wt, float tau,
                                                const lds_f32* wvec /* LDS [NS][256] */) {
+        if constexpr (ablate(0)) return;
         const int NT = (N + 15) >> 4;
         const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the hbuf units; extra rows below
         const int nch = (NMT + 3) >> 2, cbase = NMT / nch, crem = NMT % nch;    // chunk sizes differ by at most one
@@ -900,7 +952,7 @@ struct Blk {
         // Prefetch an item's W / m / v / W' NOW: their HBM latency hides under the previous item's k-loop
         // (addresses clamped, stores predicated).
         auto issue = [&](WgPre& P, int idx) {
-            if constexpr (GONLY) return;
+            if constexpr (GONLY || ablate(1)) return;
             int t, m0, nq;
             item_geom(idx, t, m0, nq);
             const bool n4ok = 16 * t + 4 * g < N;        // N % 4 == 0: all four columns valid or none
@@ -908,9 +960,13 @@ struct Blk {
             for (int q = 0; q < 4; q++) {
                 const int kp = 16 * (m0 + q) + c;
                 const size_t p = (q < nq && kp < H1 && n4ok) ? ((((size_t)(m0 + q) * NT + t) << 8) + lane4) : 0;
+                if constexpr (ablate(12)) {
+                    P.w[q] = P.m[q] = P.v[q] = P.t[q] = f32x4{0.5f, 0.25f, 0.125f, 1.0f} * alpha;
+                    continue;
+                }
                 P.w[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
-                P.m[q] = *reinterpret_cast<const f32x4*>(&mp[p]);
-                P.v[q] = *reinterpret_cast<const f32x4*>(&vp[p]);
+                P.m[q] = ld_stream(&mp[p]);
+                P.v[q] = ld_stream(&vp[p]);
                 if constexpr (!NOPOL) P.t[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
             }
         };
@@ -983,6 +1039,12 @@ struct Blk {
             else kloop(std::integral_constant<int, 0>{});
             sub_stamp(22);
             const bool n4ok = 16 * t + 4 * g < N;
+            if constexpr (ablate(1)) {       // keep the accumulators live, store nothing
+#pragma unroll
+                for (int q = 0; q < MCC; q++)
+                    if (acc[q][0] == 1.2345e33f) Wp[0] = acc[q][1] + acc[q][2] + acc[q][3];
+                return;
+            }
 #pragma unroll
             for (int q = 0; q < MCC; q++) {
                 const int kp = 16 * (m0 + q) + c;
@@ -992,6 +1054,9 @@ struct Blk {
                     continue;
                 }
                 f32x4 nw, nm = P.m[q], nv = P.v[q], nt;
+                if constexpr (ablate(13)) {
+                    nw = P.w[q] + acc[q]; nm = nm + acc[q]; nt = P.t[q] + acc[q];
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     float mm = nm[r], vv = nv[r];
@@ -999,10 +1064,15 @@ struct Blk {
                     nm[r] = mm; nv[r] = vv;
                     if constexpr (!NOPOL) nt[r] = polyak(P.t[q][r], nw[r], tau);
                 }
+                }
+                if constexpr (ablate(11)) {
+                    if (nw[0] + nm[1] + nv[2] + nt[3] == 1.2345e33f) Wp[0] = 1.0f;
+                    continue;
+                }
                 if (q < nq && kp < H1 && n4ok) {
                     const size_t p = (((size_t)(m0 + q) * NT + t) << 8) + lane4;
-                    *reinterpret_cast<f32x4*>(&mp[p]) = nm;
-                    *reinterpret_cast<f32x4*>(&vp[p]) = nv;
+                    st_stream(&mp[p], nm);
+                    st_stream(&vp[p], nv);
                     *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
                     if constexpr (!NOPOL) *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
                     if (tapp) *reinterpret_cast<f32x4*>(&tapp[p]) = acc[q];
@@ -1044,7 +1114,7 @@ struct Blk {
         sub_begin();
         // extra rows of a concat layer (rank-NE term): G[H1+j][n] = sum_b E[b][j] * D[b][n]; one N tile per
         // wave at a time
-        if constexpr (NE > 0) {
+        if constexpr (NE > 0 && !ablate(2)) {
             // waves 4-7 carry six of the 52 tile chunks above, waves 0-3 seven: the extra rows go to waves 4-7 first
             for (int t = (wave + 4) & 7; t < NT; t += kWaves) {
                 const int n = 16 * t + c;

@@ -129,6 +129,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
     if (tid < 16) L.hbuf[MB * LDH + tid] = 0.0f;
     __syncthreads();
 
+    stagger_start();
     f32x4 acc[MT][NTW];
     for (int upd = 0; upd < n_updates; upd++) {
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));     // see ddpg_mfma_kernel.h

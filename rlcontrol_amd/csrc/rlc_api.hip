@@ -133,9 +133,11 @@ int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, 
     h->idx_dev = nullptr; h->idx_cap = 0;
     h->io_dev = nullptr; h->io_cap = 0;
     h->io_host = nullptr; h->io_host_cap = 0;
+    h->aq_dev = nullptr; h->aq_host = nullptr; h->aq_cap = 0; h->aq_first = 0; h->aq_n = 0;
     h->io_pending = false;
     h->variant = 0;
     h->split_c = 1; h->split_part = nullptr; h->split_bar = nullptr; h->split_err = nullptr;
+    h->split_poisoned = false; h->split_fail_next = false;
     h->grad_taps = 0;
     h->has_env = false;
     memset(&h->env, 0, sizeof(h->env));
@@ -179,6 +181,8 @@ void rlc_h_destroy(rlc_handle* h) {
     if (h->idx_dev) (void)hipFree(h->idx_dev);
     if (h->io_dev) (void)hipFree(h->io_dev);
     if (h->io_host) (void)hipHostFree(h->io_host);
+    if (h->aq_dev) (void)hipFree(h->aq_dev);
+    if (h->aq_host) (void)hipHostFree(h->aq_host);
     if (h->st) {
         (void)hipEventDestroy(h->ev0);
         (void)hipEventDestroy(h->ev1);
@@ -515,6 +519,50 @@ int rlc_ddpg_act_explore(rlc_handle* h, int32_t first_agent, int32_t n, const do
     return act_common(h, first_agent, n, states, out_actions, 1);
 }
 
+// update(..., next_state, ...) is followed by step(next_state) (agents/base_agent.py:54-63, experiment.py:132-135): the
+// acting forward for next_state is queued on the handle's stream right behind the update that was just launched, its
+// result lands in a pinned buffer, and the host is not synchronised here -- one synchronisation per environment step,
+// in rlc_ddpg_act_fetch.
+int rlc_ddpg_act_queue(rlc_handle* h, int32_t first_agent, int32_t n, const double* states) {
+    RLC_NEED_DDPG(h);
+    if (use_device(h)) return 1;
+    RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->dv.n_agents, "agent range [%d,%d) invalid",
+                first_agent, first_agent + n);
+    RLC_REQUIRE(states, "null array");
+    const size_t S = h->dv.d.S, A = h->dv.d.A, need = sizeof(float) * n * (S + A);
+    if (need > h->aq_cap) {
+        RLC_HIP(hipStreamSynchronize(h->st));
+        if (h->aq_dev) RLC_HIP(hipFree(h->aq_dev));
+        if (h->aq_host) RLC_HIP(hipHostFree(h->aq_host));
+        h->aq_dev = nullptr; h->aq_host = nullptr; h->aq_cap = 0;
+        RLC_HIP(hipMalloc((void**)&h->aq_dev, need * 2));
+        RLC_HIP(hipHostMalloc((void**)&h->aq_host, need * 2, hipHostMallocDefault));
+        h->aq_cap = need * 2;
+    } else if (h->aq_n) {
+        RLC_HIP(hipStreamSynchronize(h->st));     // a queued forward nobody fetched still reads / writes the buffers
+    }
+    h->aq_n = 0;
+    for (size_t i = 0; i < (size_t)n * S; i++) h->aq_host[i] = (float)states[i];
+    RLC_HIP(hipMemcpyAsync(h->aq_dev, h->aq_host, sizeof(float) * n * S, hipMemcpyHostToDevice, h->st));
+    if (rlc_launch_act(h->dv, first_agent, n, h->aq_dev, h->aq_dev + n * S, 0, h->st)) return 1;
+    RLC_HIP(hipMemcpyAsync(h->aq_host + n * S, h->aq_dev + n * S, sizeof(float) * n * A, hipMemcpyDeviceToHost, h->st));
+    h->aq_first = first_agent; h->aq_n = n;
+    return 0;
+}
+
+int rlc_ddpg_act_fetch(rlc_handle* h, int32_t first_agent, int32_t n, float* out_actions) {
+    RLC_NEED_DDPG(h);
+    if (use_device(h)) return 1;
+    RLC_REQUIRE(out_actions, "null array");
+    RLC_REQUIRE(h->aq_n > 0, "no acting forward is queued (rlc_ddpg_act_queue)");
+    RLC_REQUIRE(first_agent == h->aq_first && n == h->aq_n, "queued forward is for agents [%d,%d), asked for [%d,%d)",
+                h->aq_first, h->aq_first + h->aq_n, first_agent, first_agent + n);
+    RLC_HIP(hipStreamSynchronize(h->st));
+    memcpy(out_actions, h->aq_host + (size_t)n * h->dv.d.S, sizeof(float) * n * h->dv.d.A);
+    h->aq_n = 0;
+    return 0;
+}
+
 int rlc_ddpg_reset_noise(rlc_handle* h, int32_t first_agent, int32_t n) {
     RLC_NEED_DDPG(h);
     if (use_device(h)) return 1;
@@ -571,18 +619,41 @@ static int relayout(rlc_handle* h, int blocked) {
     return 0;
 }
 
+int rlc_h_split_before_launch(rlc_handle* h) {
+    RLC_REQUIRE(!h->split_poisoned, "latency mode: an earlier update of this handle failed at a cross-workgroup barrier; its "
+                "parameters are those of the last completed phase of that update -- reload them and call set_split again");
+    const int word = h->split_fail_next ? 1 : 0;
+    h->split_fail_next = false;
+    RLC_HIP(hipMemcpyAsync(h->split_err, &word, sizeof(int), hipMemcpyHostToDevice, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));          // `word` is a stack variable
+    return 0;
+}
+
+int rlc_h_split_after_launch(rlc_handle* h) {
+    // a barrier that did not complete (a peer workgroup was not resident) must not pass for a finished update
+    int err = 0;
+    RLC_HIP(hipMemcpyAsync(&err, h->split_err, sizeof(int), hipMemcpyDeviceToHost, h->st));
+    RLC_HIP(hipStreamSynchronize(h->st));
+    if (err != 0) h->split_poisoned = true;
+    RLC_REQUIRE(err == 0, "split update: a cross-workgroup barrier did not complete (the GPU is shared with other work?); "
+                "every workgroup stopped at it, the update is incomplete and the handle refuses further latency-mode updates");
+    return 0;
+}
+
+int rlc_debug_fail_next_split(rlc_handle* h) {
+    RLC_REQUIRE(h != nullptr && h->split_err != nullptr, "latency mode is not armed on this handle (set_split)");
+    h->split_fail_next = true;
+    return 0;
+}
+
 static int launch_update(rlc_handle* h, int first, int n, int n_updates, int source, const long long* idx_dev) {
     const int v = pick_variant(h);
     if (v == 2 && h->split_c > 1) {
+        if (rlc_h_split_before_launch(h)) return 1;
         if (rlc_launch_ddpg_update_split(h->dv, h->split_part, h->split_bar, h->split_err, h->split_c, first, n, n_updates,
                                          source, idx_dev, h->grad_taps, h->st))
             return 1;
-        // a barrier that timed out (a peer workgroup was not resident) must not pass for a finished update
-        int err = 0;
-        RLC_HIP(hipMemcpyAsync(&err, h->split_err, sizeof(int), hipMemcpyDeviceToHost, h->st));
-        RLC_HIP(hipStreamSynchronize(h->st));
-        RLC_REQUIRE(err == 0, "split update: a cross-workgroup barrier timed out (the GPU is shared with other work?)");
-        return 0;
+        return rlc_h_split_after_launch(h);
     }
     if (v == 2) {
         RLC_REQUIRE(rlc_mfma_supported(h->dv.d), "MFMA kernel does not support these dimensions");
@@ -673,6 +744,7 @@ int rlc_ddpg_set_split(rlc_handle* h, int32_t n_workgroups) {
     // partial-gradient blobs: zeroed once, the kernels only ever write real parameter slots
     if (rlc_h_malloc(h, &h->split_part, (size_t)h->dv.n_agents * n_workgroups * h->dv.d.Ppad)) return 1;
     h->split_c = n_workgroups;
+    h->split_poisoned = false;           // re-armed by the caller
     return 0;
 }
 

@@ -150,6 +150,7 @@ int rlc_kl_set_split(rlc_handle* h, int32_t n_workgroups) {
         if (rlc_h_malloc(h, &h->split_part, (size_t)h->sac.n_agents * rlc_kl_split_zbuf_floats(h->sac.d))) return 1;
     }
     h->split_c = n_workgroups;
+    h->split_poisoned = false;           // re-armed by the caller
     return 0;
 }
 

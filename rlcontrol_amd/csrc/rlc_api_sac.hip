@@ -78,15 +78,11 @@ int rlc_h_sac_launch_update(rlc_handle* h, int first, int n, int n_updates, int 
                             const float* eps_dev, const RlcSacRollout* rollout) {
     if (h->algo == RLC_ALGO_KL) {
         if (rlc_h_kl_variant(h) == 2 && h->split_c > 1 && !rollout) {
+            if (rlc_h_split_before_launch(h)) return 1;
             if (rlc_launch_kl_update_mfma_split(h->sac, h->split_part, h->split_bar, h->split_err, h->split_c, first, n,
                                                 n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st))
                 return 1;
-            // a barrier that timed out (a peer workgroup was not resident) must not pass for a finished update
-            int err = 0;
-            RLC_HIP(hipMemcpyAsync(&err, h->split_err, sizeof(int), hipMemcpyDeviceToHost, h->st));
-            RLC_HIP(hipStreamSynchronize(h->st));
-            RLC_REQUIRE(err == 0, "split update: a cross-workgroup barrier timed out (the GPU is shared with other work?)");
-            return 0;
+            return rlc_h_split_after_launch(h);
         }
         if (rlc_h_kl_variant(h) == 2)
             return rlc_launch_kl_update_mfma(h->sac, first, n, n_updates, source, idx_dev, eps_dev, h->grad_taps, h->st,

@@ -21,12 +21,17 @@ struct rlc_handle {
     float* io_dev; size_t io_cap;        // act / qval / gather staging (device, bytes)
     void* io_host; size_t io_host_cap;   // pinned host staging (bytes)
     bool io_pending;                     // async copies out of io_host may still be in flight (the update_batch paths)
+    // queued acting forward (rlc_ddpg_act_queue / rlc_ddpg_act_fetch): buffers of their own, nothing else writes them
+    float* aq_dev; float* aq_host; size_t aq_cap;   // device / pinned host staging: [n][S] states then [n][A] actions
+    int aq_first, aq_n;                  // agent range of the queued forward; aq_n == 0: nothing queued
     // ---- DDPG
     RlcDev dv;
     int variant;                         // requested kernel: 0 auto, 1 generic, 2 mfma
     int grad_taps;
     int split_c;                         // > 1: latency mode, one agent's minibatch over split_c workgroups (ddpg_split.hip)
     float* split_part; unsigned int* split_bar; int* split_err;
+    bool split_poisoned;                 // a latency-mode update failed at a cross-workgroup barrier: refuse further ones
+    bool split_fail_next;                // test hook (rlc_debug_fail_next_split): the next launch finds the error word set
     // ---- SAC
     RlcSacDev sac;
     // ---- NAF
@@ -42,6 +47,16 @@ struct rlc_handle {
 };
 
 // kernel variant in use (1 generic, 2 mfma): the request h->variant (0 auto) resolved against the shape support
+// Latency-mode launches (ddpg_split.hip / kl_mfma.hip): the error word is cleared before every launch (set instead when
+// the test hook asked for a failure) and read back after it.  On failure every workgroup has left the kernel at the
+// barrier that failed, before any store of the phase behind it: parameters / optimizer state are those of the last
+// COMPLETED phase of the failed update.  The handle then refuses latency-mode updates until rlc_*_set_split re-arms it
+// (after the caller has reloaded or accepted the state).
+extern "C" {
+int rlc_h_split_before_launch(rlc_handle* h);
+int rlc_h_split_after_launch(rlc_handle* h);
+}
+
 inline int rlc_h_sac_variant(const rlc_handle* h) {
     if (h->variant == 1 || h->variant == 2) return h->variant;
     return rlc_sac_mfma_supported(h->sac.d) ? 2 : 1;

@@ -129,6 +129,17 @@ class DDPGPopulation(Population):
         check(fn(self._h, int(first_agent), ctypes.c_int32(s.shape[0]), dptr(s), fptr(out)))
         return out
 
+    def act_queue(self, states, first_agent=0):
+        """queue the greedy forward for `states` behind the work already on the handle's stream (no synchronisation)"""
+        s = f64(states).reshape(-1, self.S)
+        check(self._lib.rlc_ddpg_act_queue(self._h, int(first_agent), ctypes.c_int32(s.shape[0]), dptr(s)))
+        return s.shape[0]
+
+    def act_fetch(self, n, first_agent=0):
+        out = np.empty((int(n), self.A), np.float32)
+        check(self._lib.rlc_ddpg_act_fetch(self._h, int(first_agent), ctypes.c_int32(int(n)), fptr(out)))
+        return out
+
     def reset_noise(self, first_agent=0, n=None):
         check(self._lib.rlc_ddpg_reset_noise(self._h, int(first_agent), int(self.n_agents if n is None else n)))
 
@@ -163,6 +174,10 @@ class DDPGPopulation(Population):
     def set_split(self, n_workgroups):
         """latency mode: every agent's minibatch over n_workgroups CUs (1 = off); MFMA shapes only"""
         check(self._lib.rlc_ddpg_set_split(self._h, ctypes.c_int32(int(n_workgroups))))
+
+    def debug_fail_next_split(self):
+        """test hook: the next latency-mode launch finds its barrier error word set (include/rlcontrol_hip.h)"""
+        check(self._lib.rlc_debug_fail_next_split(self._h))
 
     def kernel_in_use(self):
         out = ctypes.c_int32(0)

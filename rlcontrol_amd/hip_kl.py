@@ -109,6 +109,9 @@ class KLPopulation(Population):
         if init_target:
             check(self._lib.rlc_kl_init_target(self._h, int(agent)))
 
+    def debug_fail_next_split(self):
+        check(self._lib.rlc_debug_fail_next_split(self._h))
+
     def set_split(self, n_workgroups):
         """latency mode: the node passes of each agent's action integral over that many CUs (1 = off)"""
         check(self._lib.rlc_kl_set_split(self._h, ctypes.c_int32(int(n_workgroups))))

@@ -6,6 +6,11 @@ forwardkl_network.py:60-70), which is not installed here; the rule itself is cla
     w_k = (c_k / n) * (1 - sum_{j=1}^{floor(n/2)} b_j / (4 j^2 - 1) * cos(2 j k pi / n)),
     c_k = 1 at the two end points and 2 inside,  b_j = 1 if 2 j == n else 2.
 The agents drop the two end points (tanh never reaches +-1) and scale the nodes by ``action_max``.
+
+Parity unpinned against quadpy itself: the library is absent and the reference holds no fixture for the rule, so the
+point ORDER (ascending here, as the reference's own comments imply) and the last bits of the fp64 values before the fp32
+cast are checked only against a second in-repo construction (Waldvogel's FFT, oracle/kl_torch.py) and polynomial
+exactness (tests/test_kl.py).
 """
 import numpy as np
 

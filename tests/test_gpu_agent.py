@@ -96,3 +96,56 @@ def test_device_sampler_mode_runs(hip_lib):
         a = agent.step(obs_n, True)
         obs = obs_n
     assert agent.replay_buffer.get_size() == 60 and np.all(np.isfinite(a))
+
+
+def _drive(agent, env, seed, steps, queued):
+    """the step loop of experiment.py:105-135; returns every action the agent chose"""
+    agent.network_manager.queues_next_action = queued
+    env.set_random_seed(seed)
+    obs = env.reset()
+    agent.reset()
+    a = agent.start(obs, True)
+    out, fetched = [a.copy()], 0
+    for t in range(steps):
+        obs_n, r, done, _ = env.step(a)
+        agent.update(obs, obs_n, float(r), a, done, False)
+        if queued and agent.network_manager._queued_state is not None:
+            fetched += 1
+        if t % 17 == 5:                                  # an evaluation episode's first action between update and step
+            agent.start(np.array([0.3, -0.2, 1.0]), False)   # (drops the queued forward: a different state)
+        a = agent.step(obs_n, True)
+        out.append(a.copy())
+        obs = obs_n
+    return np.stack(out), fetched
+
+
+def test_queued_next_action_equals_plain_acting(hip_lib):
+    """rlc_ddpg_act_queue / rlc_ddpg_act_fetch (one synchronisation per environment step): the action step() returns is
+    bit for bit the one a separate rlc_ddpg_act call computes after the update, exploration noise drawn in the same
+    order (agents/DDPG.py:36-48); a forward queued for another state is dropped, not returned."""
+    from rlcontrol_amd.utils.main_utils import create_agent
+    outs = []
+    for queued in (True, False):
+        cfg, env = _config(3, 32)
+        agent = create_agent("DDPG", cfg)
+        acts, fetched = _drive(agent, env, 3, 120, queued)
+        outs.append(acts)
+        if queued:
+            assert fetched == 120 - 32                   # every step after the first update queued its forward (Q12)
+    assert np.array_equal(outs[0], outs[1])
+    assert np.all(np.isfinite(outs[0]))
+
+
+def test_act_fetch_without_queue_is_refused(hip_lib):
+    from rlcontrol_amd._lib import RlcError
+    from rlcontrol_amd.hip_ddpg import DDPGPopulation
+    pop = DDPGPopulation(2, 3, 1, 32, 32, 32, 16, 100, 0.01, [-1, -1, -8], [1, 1, 8], [-2.0], [2.0], 1e-3, 1e-2,
+                         seeds=[1, 2])
+    with pytest.raises(RlcError, match="no acting forward is queued"):
+        pop.act_fetch(1)
+    s = np.array([[0.5, 0.1, -1.0], [0.2, -0.3, 2.0]])
+    assert pop.act_queue(s) == 2
+    with pytest.raises(RlcError, match="queued forward is for agents"):
+        pop.act_fetch(1)
+    assert np.array_equal(pop.act_fetch(2), pop.act(s))
+    pop.close()

@@ -445,3 +445,33 @@ def test_split_is_refused_where_it_cannot_run(hip_lib):
     with pytest.raises(RlcError, match="MFMA"):
         pop.set_split(2)
     pop.close()
+
+
+def test_split_barrier_failure_leaves_the_state_untouched_and_poisons_the_handle(hip_lib):
+    """A cross-workgroup barrier that does not complete (test hook: the error word is found set): every workgroup leaves
+    at the FIRST barrier, i.e. before the critic reduce / Adam -- parameters, optimizer state and targets keep their
+    bits, the call fails, and the handle refuses latency-mode updates until set_split re-arms it."""
+    from oracle.ddpg import Dims, init_params
+    from rlcontrol_amd._lib import RlcError
+    dims, B, N = (3, 1, 200, 200, 200), 100, 2000
+    rng = np.random.RandomState(5)
+    data = (rng.randn(N, 3), rng.randn(N, 1), rng.randn(N), rng.randn(N, 3), np.full(N, 0.99))
+    pop, _, _, _ = _make(dims, B, n_agents=1, cap=N, kernel="mfma")
+    pop.set_params(0, init_params(Dims(*dims), 3))
+    pop.replay_add_batch(0, *data)
+    pop.set_split(4)
+    pop.update(2)                                        # a healthy latency-mode launch first
+    before = {w: pop.get_blob(0, w) for w in ("theta", "theta_target", "critic_m", "critic_v", "actor_m", "actor_v")}
+    pw = pop.get_beta_powers(0)
+    pop.debug_fail_next_split()
+    with pytest.raises(RlcError, match="did not complete"):
+        pop.update(1)
+    for w, v in before.items():
+        assert np.array_equal(pop.get_blob(0, w), v), w   # nothing was stored behind the failed barrier
+    assert np.array_equal(pop.get_beta_powers(0), pw)
+    with pytest.raises(RlcError, match="an earlier update of this handle failed"):
+        pop.update(1)                                    # poisoned
+    pop.set_split(4)                                     # the caller re-arms (state verified above)
+    pop.update(1)
+    assert not np.array_equal(pop.get_blob(0, "theta"), before["theta"])
+    pop.close()
