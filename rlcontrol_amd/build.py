@@ -151,8 +151,35 @@ def check_spill_policy(usage):
     return bad
 
 
-def _stale(src, obj, hdr_time):
-    return (not os.path.exists(obj)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time)
+_INC_CACHE = {}
+
+
+def _deps(path):
+    """`path` and every header under csrc/ or include/ it includes, transitively (plain `#include "x.h"` scan)"""
+    import re
+    path = os.path.abspath(path)
+    if path in _INC_CACHE:
+        return _INC_CACHE[path]
+    _INC_CACHE[path] = out = {path}
+    try:
+        text = open(path).read()
+    except OSError:
+        return out
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, re.M):
+        for d in (os.path.dirname(path), CSRC, os.path.join(_HERE, "..", "include")):
+            cand = os.path.abspath(os.path.join(d, name))
+            if os.path.exists(cand):
+                out |= _deps(cand)
+                break
+    return out
+
+
+def _stale(src, obj, hdr_time=None):
+    """an object is stale when it is older than its source or any header that source includes (transitively)"""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(os.path.getmtime(f) > t for f in _deps(src))
 
 
 VARIANT_TAG = OUT + ".variant"

@@ -264,11 +264,18 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         u.template bwd_gemm<1, -2>(acc, th + d.oWc2, HC, H1, L.dq, L.wvec);
         __syncthreads();      // every wave has finished reading the pre-step Wc2 rows and W1
         STAMP();
+        // the first weight-gradient item's W / m / v / W' go in flight before the first-layer gradient, not after it
+        typename U::WgPre2 pre;
+        const typename U::WgPre2* prep = nullptr;
+#ifndef RLC_NO_EARLY_PREFETCH
+        u.template wgrad_prefetch<false, 1>(pre, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, tt + d.oWc2);
+        prep = &pre;
+#endif
         u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f, L.x);
         STAMP();
         // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue
         u.template wgrad_adam<1, AD>(L.dq, L.a, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
-                     tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau, L.wvec);
+                     tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau, L.wvec, prep);
         // small critic tensors: Wc3, bc2 (column owners), bc3 (one thread)
         {
             const int NT = (HC + 15) >> 4;
@@ -393,10 +400,13 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         u.template bwd_gemm<AD, -2>(acc, th + d.oWa2, HA, H1, L.dz, L.wvec);
         __syncthreads();
         STAMP();
+#ifndef RLC_NO_EARLY_PREFETCH
+        u.template wgrad_prefetch<false, 1>(pre, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, tt + d.oWa2);
+#endif
         u.trunk_grad_adam(acc, th, m_a, v_a, alpha_a, d.oW1, d.ob1, tap_ga, tt, tau, L.x);
         STAMP();
         u.template wgrad_adam<AD, 0>(L.dz, nullptr, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
-                     tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau, L.wvec);
+                     tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau, L.wvec, prep);
         {
             const int NT = (HA + 15) >> 4;
 #pragma unroll

@@ -36,11 +36,10 @@ struct RlcSplit {
 // another workgroup of the launch: the error word is set).  The caller returns at once: no Adam / Polyak store of a
 // phase whose inputs are incomplete is ever issued, so parameters and optimizer state stay those of the last
 // completed phase; the host reports the failure and poisons the handle (rlc_api.hip launch_update).
-__device__ __forceinline__ bool split_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err) {
+__device__ __forceinline__ bool split_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err, mfb::lds_i32* failed /* one LDS word */) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
-    __shared__ int failed;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -60,10 +59,10 @@ __device__ __forceinline__ bool split_barrier(unsigned int* ctr, int C, unsigned
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // a workgroup that passed the poll still stops when another one of the launch has failed: nobody may go on
         // to reduce partials (or read an image) its peers have not finished
-        failed = bad | __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *failed = bad | __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    return failed == 0;
+    return *failed == 0;
 }
 
 // g[p] = sum_cc part[cc][p] for the float4 groups of [lo, hi) dealt to workgroup c; Adam on (th, m, v) with alpha;
@@ -264,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_split_kernel(RlcDev 
         u.template trunk_grad_adam<NoExtra, true>(acc, nullptr, nullptr, nullptr, 0.0f, d.oW1, d.ob1, mine, nullptr, 0.0f, L.x);
         u.template wgrad_adam<1, AD, -2, true>(L.dq, L.a, HC, nullptr, nullptr, nullptr, 0.0f, mine + d.oWc2, nullptr, 0.0f,
                                                L.wvec);
-        if (!split_barrier(ctr, C, gen, sp.err)) return;
+        if (!split_barrier(ctr, C, gen, sp.err, L.dups + 3)) return;
         // ---- reduce + critic Adam on my slice: trunk [0, oWa2) without target update, critic block with it ----
         {
             const float alpha_c = adam_alpha(lr_c, pw2, pw3);
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_split_kernel(RlcDev 
                                  d.Pdev, tap_gc);
             pw2 *= 0.9f; pw3 *= 0.999f;
         }
-        if (!split_barrier(ctr, C, gen, sp.err)) return;
+        if (!split_barrier(ctr, C, gen, sp.err, L.dups + 3)) return;
 
         // ================= step 4: actor forward with the updated trunk =================
         u.trunk(th + d.oW1, th + d.ob1, L.x);
@@ -370,13 +369,13 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_split_kernel(RlcDev 
         u.template trunk_grad_adam<NoExtra, true>(acc, nullptr, nullptr, nullptr, 0.0f, d.oW1, d.ob1, mine, nullptr, 0.0f, L.x);
         u.template wgrad_adam<AD, 0, -2, true>(L.dz, nullptr, HA, nullptr, nullptr, nullptr, 0.0f, mine + d.oWa2, nullptr, 0.0f,
                                                L.wvec);
-        if (!split_barrier(ctr, C, gen, sp.err)) return;
+        if (!split_barrier(ctr, C, gen, sp.err, L.dups + 3)) return;
         {
             const float alpha_a = adam_alpha(lr_a, pw0, pw1);
             split_reduce_adam<U>(parts, pstride, C, c, 0, d.ocritic0, th, m_a, v_a, alpha_a, tt, tau, 0, d.ocritic0, tap_ga);
             pw0 *= 0.9f; pw1 *= 0.999f;
         }
-        if (!split_barrier(ctr, C, gen, sp.err)) return;
+        if (!split_barrier(ctr, C, gen, sp.err, L.dups + 3)) return;
     }
     if (c == 0 && tid == 0) {
         pw[0] = pw0; pw[1] = pw1; pw[2] = pw2; pw[3] = pw3;

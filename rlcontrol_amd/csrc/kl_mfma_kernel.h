@@ -53,11 +53,10 @@ struct KlSplit {
 // another workgroup of the launch: the error word is set).  The caller returns at once: no Adam / Polyak store of a
 // phase whose inputs are incomplete is ever issued, so parameters and optimizer state stay those of the last
 // completed phase; the host reports the failure and poisons the handle (rlc_api.hip launch_update).
-__device__ __forceinline__ bool kl_group_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err) {
+__device__ __forceinline__ bool kl_group_barrier(unsigned int* ctr, int C, unsigned int& gen, int* err, mfb::lds_i32* failed /* one LDS word */) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     gen += 1;
-    __shared__ int failed;
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -77,10 +76,10 @@ __device__ __forceinline__ bool kl_group_barrier(unsigned int* ctr, int C, unsig
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // a workgroup that passed the poll still stops when another one of the launch has failed: nobody may go on
         // to reduce partials (or read an image) its peers have not finished
-        failed = bad | __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *failed = bad | __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    return failed == 0;
+    return *failed == 0;
 }
 
 struct KSmem {
@@ -262,13 +261,13 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
             // helper: per update, the owner's z1s image and the current Q weights -> my passes
             float* zb = sp.zbuf + (size_t)rel_agent * MB * LDH;
             for (int upd = 0; upd < n_updates; upd++) {
-                if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return;
+                if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err, L.dups + 3)) return;
                 for (int i = tid; i < (MB * LDH) >> 2; i += kThreads)
                     reinterpret_cast<lds_f32x4*>(L.z1s)[i] = reinterpret_cast<const f32x4*>(zb)[i];
                 for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;
                 __syncthreads();
                 node_passes();
-                if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return;
+                if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err, L.dups + 3)) return;
             }
             return;
         }
@@ -459,9 +458,9 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
             }
             for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;
             __syncthreads();
-            if constexpr (SPLIT) { if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return; }     // z1s published
+            if constexpr (SPLIT) { if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err, L.dups + 3)) return; }     // z1s published
             node_passes();
-            if constexpr (SPLIT) { if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err)) return; }     // every pass has landed
+            if constexpr (SPLIT) { if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err, L.dups + 3)) return; }     // every pass has landed
             __syncthreads();
             // ================= 7: one wave per state: log pi at the nodes, d loss / d lp, seeds of mean and log_std =================
             for (int b = u.wave; b < B; b += kWaves) {

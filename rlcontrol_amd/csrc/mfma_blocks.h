@@ -79,8 +79,17 @@ constexpr int SMAX = 8;       // state rows are padded to 8 floats in LDS (two d
 // backward GEMM (row 16mt+c, bytes nc+4g..+3) sits in bank (4*odd*c + g + const) mod 64: conflict-free for all lanes.
 constexpr int mask_stride(int nt16) { return ((nt16 + 1) & 1) ? 16 * (nt16 + 1) : 16 * (nt16 + 2); }
 
-// Adam's m / v slots are touched once per update: with RLC_NT_STATE they are loaded / stored non-temporally (the `nt`
-// bit), so that they do not displace the weight matrices the GEMMs re-read from L2 / the Infinity Cache
+// Adam's m / v slots are touched once per update, the target matrix twice (its forward GEMM and this epilogue): they are
+// loaded / stored non-temporally (the `nt` bit), so that they do not displace the weight matrices the GEMMs re-read from
+// L2 / the Infinity Cache several times per update.  Measured on one box, 256 agents (profiles/r03_variant_timings_*):
+// m / v: DDPG +3.5 %, SoftActorCritic +8 %, NAF +3.7 %; the target stream on top: DDPG +1.3 %, NAF +3 %, SAC +-0.
+// -DRLC_NO_NT_STATE / -DRLC_NO_NT_TARGET switch them off for A/B runs.
+#ifndef RLC_NO_NT_STATE
+#define RLC_NT_STATE 1
+#endif
+#ifndef RLC_NO_NT_TARGET
+#define RLC_NT_TARGET 1
+#endif
 __device__ __forceinline__ f32x4 ld_stream(const float* p) {
 #ifdef RLC_NT_STATE
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
@@ -90,6 +99,21 @@ __device__ __forceinline__ f32x4 ld_stream(const float* p) {
 }
 __device__ __forceinline__ void st_stream(float* p, f32x4 v) {
 #ifdef RLC_NT_STATE
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
+__device__ __forceinline__ f32x4 ld_target(const float* p) {
+#ifdef RLC_NT_TARGET
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void st_target(float* p, f32x4 v) {
+#ifdef RLC_NT_TARGET
     __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 #else
     *reinterpret_cast<f32x4*>(p) = v;
@@ -926,6 +950,59 @@ struct Blk {
     // already in flight into a second register set.
     // ---------------------------------------------------------------------------------------
     struct WgPre { f32x4 w[4], m[4], v[4], t[4]; };
+    // the first two items of this wave (idx = wave, wave + 8) in flight before wgrad_adam is entered: wgrad_prefetch
+    // issues them ahead of the backward GEMM that precedes the weight-gradient phase, so that their HBM latency hides
+    // under that GEMM instead of under one k-loop (a wave has only two items per matrix at widths <= 128)
+    struct WgPre2 { WgPre a, b; int n; };      // n: how many of the two are in flight (1: only a)
+
+    // item idx of a [H1 x N] matrix -> N tile t, first M' tile m0, tiles in the chunk nq
+    __device__ __forceinline__ void wg_item_geom(int idx, int N, int& t, int& m0, int& nq) const {
+        const int NT = (N + 15) >> 4, NMT = (H1 + 15) >> 4;
+        const int nch = (NMT + 3) >> 2, cbase = NMT / nch, crem = NMT % nch;
+        t = idx % NT;
+        const int ch = idx / NT;
+        nq = cbase + (ch < crem ? 1 : 0);
+        m0 = ch * cbase + (ch < crem ? ch : crem);
+    }
+    __device__ __forceinline__ int wg_nitems(int N) const {
+        const int NT = (N + 15) >> 4, NMT = (H1 + 15) >> 4;
+        return NT * ((NMT + 3) >> 2);
+    }
+    // Prefetch an item's W / m / v / W' NOW (addresses clamped, stores predicated).
+    template <bool NOPOL>
+    __device__ __forceinline__ void wg_issue(WgPre& P, int idx, int N, const float* Wp, const float* mp, const float* vp,
+                                             const float* Wt, float alpha) const {
+        int t, m0, nq;
+        wg_item_geom(idx, N, t, m0, nq);
+        const int NT = (N + 15) >> 4;
+        const int lane4 = (g * 16 + c) << 2;
+        const bool n4ok = 16 * t + 4 * g < N;        // N % 4 == 0: all four columns valid or none
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kp = 16 * (m0 + q) + c;
+            const size_t p = (q < nq && kp < H1 && n4ok) ? ((((size_t)(m0 + q) * NT + t) << 8) + lane4) : 0;
+            if constexpr (ablate(12)) {
+                P.w[q] = P.m[q] = P.v[q] = P.t[q] = f32x4{0.5f, 0.25f, 0.125f, 1.0f} * alpha;
+                continue;
+            }
+            P.w[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
+            P.m[q] = ld_stream(&mp[p]);
+            P.v[q] = ld_stream(&vp[p]);
+            if constexpr (!NOPOL) P.t[q] = ld_target(&Wt[p]);
+        }
+    }
+    template <bool NOPOL = false, int NPRE = 2>
+    __device__ __forceinline__ void wgrad_prefetch(WgPre2& pre, int N, const float* Wp, const float* mp, const float* vp,
+                                                   const float* Wt) const {
+        pre.n = NPRE;
+        if constexpr (ablate(0) || ablate(1)) return;
+        const int nitems = wg_nitems(N);
+        asm volatile("" ::: "memory");
+        if (wave < nitems) wg_issue<NOPOL>(pre.a, wave, N, Wp, mp, vp, Wt, 0.0f);
+        if constexpr (NPRE > 1)
+            if (wave + kWaves < nitems) wg_issue<NOPOL>(pre.b, wave + kWaves, N, Wp, mp, vp, Wt, 0.0f);
+        asm volatile("" ::: "memory");
+    }
 
     // GONLY: as in trunk_grad_adam -- the gradient tiles go to `tapp` (not null), nothing else is read or written.
     // NOPOL: the matrix has no target copy (Wt unused): no target loads, no Polyak stores.
@@ -933,7 +1010,7 @@ struct Blk {
     __device__ __forceinline__ void wgrad_adam(const lds_f32* seed /* LDS [MB][NS] */, const lds_f32* E /* LDS [MB][NE] or null */,
                                                int N, float* Wp, float* mp, float* vp,
                                                float alpha, float* tapp, float* Wt, float tau,
-                                               const lds_f32* wvec /* LDS [NS][256] */) {
+                                               const lds_f32* wvec /* LDS [NS][256] */, const WgPre2* pre = nullptr) {
         if constexpr (ablate(0)) return;
         const int NT = (N + 15) >> 4;
         const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the hbuf units; extra rows below
@@ -943,35 +1020,17 @@ struct Blk {
         const int lane4 = (g * 16 + c) << 2;
         constexpr unsigned MBITS = BIT < 0 ? 0xffu : (1u << (BIT < 0 ? 0 : BIT));
 
-        auto item_geom = [&](int idx, int& t, int& m0, int& nq) {
-            t = idx % NT;
-            const int ch = idx / NT;
-            nq = cbase + (ch < crem ? 1 : 0);
-            m0 = ch * cbase + (ch < crem ? ch : crem);
-        };
+        auto item_geom = [&](int idx, int& t, int& m0, int& nq) { wg_item_geom(idx, N, t, m0, nq); };
         // Prefetch an item's W / m / v / W' NOW: their HBM latency hides under the previous item's k-loop
-        // (addresses clamped, stores predicated).
         auto issue = [&](WgPre& P, int idx) {
             if constexpr (GONLY || ablate(1)) return;
-            int t, m0, nq;
-            item_geom(idx, t, m0, nq);
-            const bool n4ok = 16 * t + 4 * g < N;        // N % 4 == 0: all four columns valid or none
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int kp = 16 * (m0 + q) + c;
-                const size_t p = (q < nq && kp < H1 && n4ok) ? ((((size_t)(m0 + q) * NT + t) << 8) + lane4) : 0;
-                if constexpr (ablate(12)) {
-                    P.w[q] = P.m[q] = P.v[q] = P.t[q] = f32x4{0.5f, 0.25f, 0.125f, 1.0f} * alpha;
-                    continue;
-                }
-                P.w[q] = *reinterpret_cast<const f32x4*>(&Wp[p]);
-                P.m[q] = ld_stream(&mp[p]);
-                P.v[q] = ld_stream(&vp[p]);
-                if constexpr (!NOPOL) P.t[q] = *reinterpret_cast<const f32x4*>(&Wt[p]);
-            }
+            wg_issue<NOPOL>(P, idx, N, Wp, mp, vp, Wt, alpha);
         };
-        auto run = [&](const WgPre& P, int idx, auto mcc_tag) {
+        // EXACT: the item has exactly MCC tiles (no aliased rows): the MCC activation reads of a k-step are then
+        // base + q * 64 B with a compile-time stride and pair up as ds_read2_b32
+        auto run = [&](const WgPre& P, int idx, auto mcc_tag, auto exact_tag) {
             constexpr int MCC = decltype(mcc_tag)::value;
+            constexpr bool EXACT = decltype(exact_tag)::value;
             int t, m0, nq;
             item_geom(idx, t, m0, nq);
             const int n = 16 * t + c;
@@ -983,7 +1042,7 @@ struct Blk {
 #pragma unroll
             for (int q = 0; q < MCC; q++) {
                 acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                kq[q] = (q < nq ? 16 * (m0 + q) : 0) + c;             // rows past the chunk alias tile 0 (never stored)
+                kq[q] = (EXACT || q < nq ? 16 * (m0 + q) : 0) + c;    // rows past the chunk alias tile 0 (never stored)
             }
             const lds_u8* mrow = L.mask + 16 * t + c;
             sub_begin();
@@ -996,7 +1055,7 @@ struct Blk {
                 const int ld = LDC ? LDC : LDH;
                 const lds_f32* hq[MCC];
 #pragma unroll
-                for (int q = 0; q < MCC; q++) hq[q] = L.hbuf + gperm * ld + kq[q];
+                for (int q = 0; q < MCC; q++) hq[q] = EXACT ? L.hbuf + gperm * ld + kq[0] + 16 * q : L.hbuf + gperm * ld + kq[q];
                 const lds_f32* sp = seed + gperm * NS;
                 const lds_u8* mp = mrow + gperm * MSTRIDE;
                 auto load_ops = [&](Ops& o, int gi) {
@@ -1074,7 +1133,7 @@ struct Blk {
                     st_stream(&mp[p], nm);
                     st_stream(&vp[p], nv);
                     *reinterpret_cast<f32x4*>(&Wp[p]) = nw;
-                    if constexpr (!NOPOL) *reinterpret_cast<f32x4*>(&Wt[p]) = nt;
+                    if constexpr (!NOPOL) st_target(&Wt[p], nt);
                     if (tapp) *reinterpret_cast<f32x4*>(&tapp[p]) = acc[q];
                 }
             }
@@ -1082,23 +1141,38 @@ struct Blk {
         };
         auto run_any = [&](const WgPre& P, int idx) {
             const int ch = idx / NT;
-            if (cbase + (ch < crem ? 1 : 0) == 4) run(P, idx, std::integral_constant<int, 4>{});
-            else run(P, idx, std::integral_constant<int, 3>{});      // chunks of < 3 tiles alias tile 0 (never stored)
+            const int nq = cbase + (ch < crem ? 1 : 0);
+#ifndef RLC_WG_EXACT      // per translation unit: +4 % for SoftActorCritic (widths <= 128), -1.5 % for DDPG (register pressure)
+            if (nq == 4) run(P, idx, std::integral_constant<int, 4>{}, std::false_type{});
+            else run(P, idx, std::integral_constant<int, 3>{}, std::false_type{});
+#else
+            if (nq == 4) run(P, idx, std::integral_constant<int, 4>{}, std::true_type{});
+            else if (nq == 3) run(P, idx, std::integral_constant<int, 3>{}, std::true_type{});
+            else run(P, idx, std::integral_constant<int, 3>{}, std::false_type{});      // chunks of < 3 tiles alias tile 0 (never stored)
+#endif
         };
 
         WgPre PA, PB;
         int idx = wave;
+#ifdef RLC_WG_STAGGER
+        // waves 4-7 (the SIMD partners of waves 0-3) start their items late: one wave of a SIMD is then in a k-loop (matrix
+        // pipe) while the other streams an epilogue (memory), instead of both doing the same thing at the same time
+        if (wave >= 4) __builtin_amdgcn_s_sleep(RLC_WG_STAGGER);      // units of 64 cycles
+#endif
         sub_begin();
         // Compiler-level memory barriers pin the prefetch loads and the epilogue stores where they are written:
         // without them hipcc reorders the overlapped prefetch across the stores of the previous item / previous
         // update (K updates in one launch then differ from K launches; tests/test_gpu_ddpg.py pins this).
 #define RLC_CBAR() asm volatile("" ::: "memory")
         RLC_CBAR();
-        if (idx < nitems) issue(PA, idx);
+        bool first = true;
+        if (pre) { PA = pre->a; if (pre->n > 1) PB = pre->b; }          // already in flight (wgrad_prefetch)
+        else if (idx < nitems) issue(PA, idx);
         sub_stamp(21);
         while (idx < nitems) {
             RLC_CBAR();
-            if (idx + kWaves < nitems) issue(PB, idx + kWaves);
+            if (idx + kWaves < nitems && !(pre && first && pre->n > 1)) issue(PB, idx + kWaves);
+            first = false;
             RLC_CBAR();
             run_any(PA, idx);
             RLC_CBAR();

@@ -327,6 +327,13 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         if (u.split_mode((L1 + 15) >> 4)) __syncthreads();      // the split tile's hand-off buffer is reused
         u.template bwd_gemm<AD, 0, true>(acc, th + d.Wa2, L2, L1, L.dz, L.wvec);
         __syncthreads();
+        // the first weight-gradient item's W / m / v / W' go in flight before the first-layer and head gradients
+        typename U::WgPre2 pre;
+        const typename U::WgPre2* prep = nullptr;
+#ifndef RLC_NO_EARLY_PREFETCH
+        u.template wgrad_prefetch<false, 1>(pre, L2, th + d.Wa2, mm + d.Wa2, vv + d.Wa2, tt + d.Wa2);
+        prep = &pre;
+#endif
         u.trunk_grad_adam(acc, th, mm, vv, alpha, d.W1, d.b1, tapg, tt, tau, L.x, [&](int b, int k) {
             const f32x4 dh = *reinterpret_cast<const lds_f32x4*>(&L.dhd[b * NHP]);
             float e = 0.0f;
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         }
         // ================= 6: the two L1 x L2 matrices, Adam + Polyak in the GEMM epilogues =================
         u.template wgrad_adam<AD, 0, 0>(L.dz, nullptr, L2, th + d.Wa2, mm + d.Wa2, vv + d.Wa2, alpha,
-                                        tapg ? tapg + d.Wa2 : nullptr, tt + d.Wa2, tau, L.wvec);
+                                        tapg ? tapg + d.Wa2 : nullptr, tt + d.Wa2, tau, L.wvec, prep);
         u.template wgrad_adam<1, 0, 1>(L.dV, nullptr, L2, th + d.Wv2, mm + d.Wv2, vv + d.Wv2, alpha,
                                        tapg ? tapg + d.Wv2 : nullptr, tt + d.Wv2, tau, wv3);
         {

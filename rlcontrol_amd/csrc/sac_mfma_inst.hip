@@ -1,5 +1,8 @@
 // sac_mfma_inst.hip -- one instantiation of the MFMA SAC kernel per translation unit
 // (compiled once per (RLC_MT, RLC_NTW, RLC_AD) triple by rlcontrol_amd/build.py so the variants build in parallel).
+#ifndef RLC_WG_NO_EXACT
+#define RLC_WG_EXACT 1      // mfma_blocks.h wgrad_adam: paired activation reads in exact items (+4 % at widths <= 128)
+#endif
 #include "sac_mfma_kernel.h"
 
 #ifndef RLC_MT

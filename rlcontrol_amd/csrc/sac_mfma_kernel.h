@@ -339,11 +339,19 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         }
         const float alpha_p = adam_alpha(dv.pi_lr[agent], pw[0], pw[1]);
         const float alpha_v = adam_alpha(dv.qv_lr[agent], pw[2], pw[3]);
+        // this wave's first two weight-gradient items of pW2 (all it has at widths <= 128): W / m / v / W' in flight NOW,
+        // under the backward GEMM, not under one k-loop (RLC_NO_EARLY_PREFETCH: the round-2 order, for A/B runs)
+        typename U::WgPre2 pre;
+        const typename U::WgPre2* prep = nullptr;
+#ifndef RLC_NO_EARLY_PREFETCH
+        u.wgrad_prefetch(pre, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, tt + d.pW2);
+        prep = &pre;
+#endif
         u.template bwd_gemm<NS, 0>(acc, th + d.pW2, L2A, L1A, L.dml, L.wvec);
         __syncthreads();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_p, d.pW1, d.pb1, tapg, tt, tau, L.xc);
         u.template wgrad_adam<NS, 0, 0>(L.dml, nullptr, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, alpha_p,
-                                        tapg ? tapg + d.pW2 : nullptr, tt + d.pW2, tau, L.wvec);
+                                        tapg ? tapg + d.pW2 : nullptr, tt + d.pW2, tau, L.wvec, prep);
         {
             const int NT = (L2A + 15) >> 4;
 #pragma unroll
@@ -377,11 +385,14 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         u.trunk(th + d.qW1, th + d.qb1, L.x);
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < L2C ? th[d.qW3 + n] : 0.0f;
         __syncthreads();
+#ifndef RLC_NO_EARLY_PREFETCH
+        u.wgrad_prefetch(pre, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, tt + d.qW2);
+#endif
         u.template bwd_gemm<1, 1>(acc, th + d.qW2, L2C, L1C, L.dout, L.wvec);
         __syncthreads();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_v, d.qW1, d.qb1, tapg, tt, tau, L.x);
         u.template wgrad_adam<1, AD, 1>(L.dout, L.a, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, alpha_v,
-                                        tapg ? tapg + d.qW2 : nullptr, tt + d.qW2, tau, L.wvec);
+                                        tapg ? tapg + d.qW2 : nullptr, tt + d.qW2, tau, L.wvec, prep);
         {
             const int NT = (L2C + 15) >> 4;
 #pragma unroll
@@ -456,11 +467,14 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 g_vb2[i] = col4_sum(s2);
             }
         }
+#ifndef RLC_NO_EARLY_PREFETCH
+        u.wgrad_prefetch(pre, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, tt + d.vW2);
+#endif
         u.template bwd_gemm<1, 0>(acc, th + d.vW2, L2C, L1C, L.dvs, L.wvec);
         __syncthreads();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_v, d.vW1, d.vb1, tapg, tt, tau, L.xc);
         u.template wgrad_adam<1, 0, 0>(L.dvs, nullptr, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, alpha_v,
-                                       tapg ? tapg + d.vW2 : nullptr, tt + d.vW2, tau, L.wvec);
+                                       tapg ? tapg + d.vW2 : nullptr, tt + d.vW2, tau, L.wvec, prep);
         {
             const int NT = (L2C + 15) >> 4;
 #pragma unroll

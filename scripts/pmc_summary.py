@@ -34,7 +34,11 @@ def main():
     ap.add_argument("--agents", type=int, default=256)
     ap.add_argument("--kernel", default="rlc_ddpg_update_mfma_kernel")
     ap.add_argument("--tag", default="r01")
+    ap.add_argument("--algorithmic-bytes", type=float, default=None, help="per update; default by kernel name")
     a = ap.parse_args()
+    algo_bytes = a.algorithmic_bytes
+    if algo_bytes is None:      # bench.py's figures
+        algo_bytes = {"rlc_sac": 51716 * 32 + 3600.0, "rlc_naf": 83406 * 32 + 8000.0}.get(a.kernel[:7], 2634064.0)
     f_kb, nf = mean_kb(a.fetch, "FETCH_SIZE", a.kernel)
     w_kb, nw = mean_kb(a.write, "WRITE_SIZE", a.kernel)
     per = a.updates_per_launch * a.agents
@@ -45,8 +49,11 @@ def main():
         "write_bytes_per_update": w_kb * 1024.0 / per,
         "traffic_bytes_per_launch_upper": (2 * f_kb + w_kb) * 1024.0,
         "traffic_bytes_per_launch_lower": (f_kb + w_kb) * 1024.0,
-        "algorithmic_bytes_per_update": 2634064,
-        "note": "FETCH_SIZE doubled for 16 B/lane streams per MI355X_MICROARCH.md; dword-load share uncalibrated -> interval",
+        "algorithmic_bytes_per_update": algo_bytes,
+        "traffic_bytes_per_update": (2 * f_kb + w_kb) * 1024.0 / per,
+        "traffic_over_algorithmic": (2 * f_kb + w_kb) * 1024.0 / per / algo_bytes,
+        "note": "traffic = 2 x FETCH_SIZE + WRITE_SIZE: profiles/r03_peaks.json calibrates FETCH_SIZE at one half of the bytes read "
+                "for the k-loop's dword stream as well as for 16 B/lane streams (the *_lower field is kept for older readers)",
     }
     path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % a.tag)
     with open(path, "w") as f:
