@@ -140,7 +140,7 @@ def cpu_baseline(seconds=15.0, records=REPLAY_N, all_cores=True):
     return out
 
 
-PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+PMC_FILES = ("r03_ddpg_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
 def pmc_traffic(n_agents, updates_per_launch, kernel):

@@ -50,10 +50,13 @@ class BaseAgent(object):
     def update(self, state, next_state, reward, action, is_terminal, is_truncated):
         if not is_truncated:
             self.replay_buffer.add(state, action, reward, next_state, self._transition_gamma(is_terminal))
-        if self.norm_type != 'none':
-            self.network_manager.input_norm.update(np.array([state]))
         # Experiment asks step(next_state) next unless the episode ended here (experiment.py:127-135)
         self.learn(None if (is_terminal or is_truncated) else next_state)
+        # the running statistics nothing reads (Q6) are fed AFTER the update was launched: the reference feeds them
+        # before learn() (agents/base_agent.py:60-62), but they touch neither the networks nor any random stream, and
+        # here their ten microseconds of numpy then run while the GPU works
+        if self.norm_type != 'none':
+            self.network_manager.input_norm.update(np.array([state]))
 
     def learn(self, next_state=None):
         ready = self.replay_buffer.get_size() > max(self.warmup_steps, self.batch_size)

@@ -195,8 +195,8 @@ def needs_build():
     except OSError:
         return True
     t = os.path.getmtime(OUT)
-    srcs = [u[0] for u in _units()] + _headers()
-    return any(os.path.getmtime(f) > t for f in srcs)
+    # an object older than one of its sources, or the library older than an object (an edit made while a build ran)
+    return any(_stale(u[0], u[1]) or os.path.getmtime(u[1]) > t for u in _units())
 
 
 def build(force=False, verbose=False, jobs=None):

@@ -292,8 +292,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_generic_kernel(RlcDe
 
 // greedy action (+ optional device OU noise) for one state per agent: predict_action on B=1
 // (agents/DDPG.py:36-44; utils/exploration_policy.py:18-21).  One workgroup per agent.
+// done_flag (or null): a word in host-visible memory that receives done_val once every action of the launch is stored
+// (single-workgroup launches only: the queued forward of a drop-in agent, rlc_ddpg_act_queue)
 __global__ __launch_bounds__(kThreads) void rlc_ddpg_act_kernel(RlcDev dv, int first_agent, const float* states,
-                                                                float* out, int explore) {
+                                                                float* out, int explore, int* done_flag, int done_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcDims d = dv.d;
     const int S = d.S, A = d.A;
@@ -311,6 +313,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_act_kernel(RlcDev dv, int f
     }
     __syncthreads();
     if (explore && tid == 0) dv.noise_ctr[agent] += 1;
+    if (done_flag && tid == 0) {
+        __threadfence_system();                     // the action stores (tid < A, ordered by the barrier above) first
+        __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ void rlc_reset_noise_kernel(RlcDev dv, int first_agent, int n) {
@@ -389,10 +395,11 @@ int rlc_launch_ddpg_update_generic(const RlcDev& dv, int first_agent, int n_agen
 }
 
 int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states_dev, float* out_dev, int explore,
-                   hipStream_t st) {
+                   hipStream_t st, int* done_flag, int done_val) {
     const size_t lds = sizeof(float) * ddpg_policy_lds_floats(dv.d);
+    RLC_REQUIRE(done_flag == nullptr || n == 1, "a completion flag needs a one-workgroup acting launch");
     hipLaunchKernelGGL(rlc_ddpg_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, out_dev,
-                       explore);
+                       explore, done_flag, done_val);
     RLC_HIP(hipGetLastError());
     return 0;
 }

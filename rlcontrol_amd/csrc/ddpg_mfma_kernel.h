@@ -30,6 +30,7 @@ struct Smem {
     lds_i32* pool;
     lds_i32* dups;
     lds_f32x4* xbuf;    // hand-off of the split 13th tile (mfma_blocks.h)
+    lds_f32 *w1t, *w1o; // first layer staged in LDS ([S][H1] weights, [H1] biases): target / online (mfma_blocks.h stage_*)
 };
 
 // carve the dynamic LDS; base may be null (host: only the size is wanted)
@@ -63,6 +64,12 @@ __host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, lds_u8* b
     L.pool = (lds_i32*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     L.dups = (lds_i32*)take(sizeof(int) * 4);
     L.xbuf = (lds_f32x4*)take(sizeof(float) * 4 * 64 * (MT - (MT + 3) / 4));
+#ifdef RLC_W1_STAGE
+    L.w1t = (lds_f32*)take(sizeof(float) * (d.S + 1) * d.H1);
+    L.w1o = (lds_f32*)take(sizeof(float) * (d.S + 1) * d.H1);
+#else
+    L.w1t = L.w1o = nullptr;
+#endif
     if (out) *out = L;
     return off;
 }
@@ -147,6 +154,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             // (agents/base_agent.py:65-70).  hbuf is free here (the trunk overwrites it below).
             if (!rlc_train_step_device(rollout, agent, (float*)L.hbuf, upd == 0 ? q8_first : 0)) continue;
         }
+#ifdef RLC_W1_STAGE
+        // both first layers go in flight now and land in LDS behind the minibatch gather
+        float stg_t[U::kStage], stg_o[U::kStage];
+        u.stage_load(stg_t, tt + d.oW1, tt + d.ob1);
+        u.stage_load(stg_o, th + d.oW1, th + d.ob1);
+#endif
         // ================= sample + gather (utils/replaybuffer.py:32-37) =================
         if (!(ablate(4) && upd > 0)) {
         u.sub_begin();
@@ -182,28 +195,36 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         }
         u.sub_stamp(27);
         }
-        __syncthreads();
+#ifdef RLC_W1_STAGE
+        u.stage_store(stg_t, L.w1t);
+        u.stage_store(stg_o, L.w1o);
+#endif
+        lds_barrier();
         STAMP();
 
         // ================= steps 1-2: target networks on s' (DDPG.py:77) =================
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1t, (const lds_f32*)(L.w1t + S * H1), L.x2);
+#else
         u.trunk(tt + d.oW1, tt + d.ob1, L.x2);
-        __syncthreads();
+#endif
+        lds_barrier();
         STAMP();
         u.fwd_gemm(acc, tt + d.oWa2, HA, H1);
         u.template bias_relu<0>(acc, tt + d.oba2, HA);
         u.template row_dot<false, AD>(acc, HA, [&](int n, int j) { return tt[d.oWa3 + n * AD + j]; }, L.part);   // z' partials
-        __syncthreads();
+        lds_barrier();
         STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
             L.aout[i] = tanhf(u.template part_sum<AD>(L.part, b, j) + tt[d.oba3 + j]) * amax[j];
         }
-        __syncthreads();
+        lds_barrier();
         STAMP();
         u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
         u.template bias_relu<AD>(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2, d.arow0);
         u.template row_dot<false, 1>(acc, HC, [&](int n, int) { return tt[d.oWc3 + n]; }, L.part);      // q' partials
-        __syncthreads();
+        lds_barrier();
         STAMP();
         for (int b = tid; b < B; b += kThreads) {
             const float qt = u.template part_sum<1>(L.part, b, 0) + tt[d.obc3];
@@ -211,18 +232,22 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             L.y[b] = y;
             dv.tap_y[(size_t)agent * RLC_MAX_BATCH + b] = y;
         }
-        __syncthreads();
+        lds_barrier();
         STAMP();
 
         // ================= step 3: critic step =================
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1o, (const lds_f32*)(L.w1o + S * H1), L.x);
+#else
         u.trunk(th + d.oW1, th + d.ob1, L.x);
+#endif
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < HC ? th[d.oWc3 + n] : 0.0f;
-        __syncthreads();
+        lds_barrier();
         STAMP();
         u.fwd_gemm(acc, th + d.oWc2, HC, H1);
         u.template bias_relu<AD>(acc, th + d.obc2, HC, L.a, th + d.oWc2, d.arow0);
         u.template row_dot<false, 1>(acc, HC, [&](int n, int) { return th[d.oWc3 + n]; }, L.part);      // q partials
-        __syncthreads();
+        lds_barrier();
         STAMP();
         for (int b = tid; b < B; b += kThreads) {
             const float q = u.template part_sum<1>(L.part, b, 0) + th[d.obc3];
@@ -230,7 +255,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             dv.tap_q[(size_t)agent * RLC_MAX_BATCH + b] = q;
             L.dq[b] = 2.0f * (q - L.y[b]) / (float)B;                  // d mean((y-q)^2)/dq
         }
-        __syncthreads();
+        lds_barrier();
         STAMP();
         // wave-local column reductions from the live g2 accumulators: dWc3, dbc2; then the relu masks
         float g_wc3[NTW], g_bc2[NTW];
@@ -257,25 +282,30 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             }
         }
         u.template store_masks<-2, true>(acc, HC);
-        __syncthreads();
+        lds_barrier();
         STAMP();
         // dh1 = (dg2 . Wc2[:H1]^T) * relu'(h1) -> W1/b1 gradients -> critic Adam on the trunk (Q1)
         const float alpha_c = adam_alpha(lr_c, pw[2], pw[3]);
         u.template bwd_gemm<1, -2>(acc, th + d.oWc2, HC, H1, L.dq, L.wvec);
-        __syncthreads();      // every wave has finished reading the pre-step Wc2 rows and W1
+        lds_barrier();      // every wave has finished reading the pre-step Wc2 rows and W1
         STAMP();
         // the first weight-gradient item's W / m / v / W' go in flight before the first-layer gradient, not after it
         typename U::WgPre2 pre;
-        const typename U::WgPre2* prep = nullptr;
-#ifndef RLC_NO_EARLY_PREFETCH
+#ifdef RLC_EARLY_PREFETCH
+        constexpr int NPRE = 1;
         u.template wgrad_prefetch<false, 1>(pre, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, tt + d.oWc2);
-        prep = &pre;
+#else
+        constexpr int NPRE = 0;
 #endif
+#ifdef RLC_W1_STAGE
+        u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f, L.x, NoExtra{}, L.w1o);   // step 4 reads the stepped trunk
+#else
         u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f, L.x);
+#endif
         STAMP();
         // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue
-        u.template wgrad_adam<1, AD>(L.dq, L.a, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
-                     tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau, L.wvec, prep);
+        u.template wgrad_adam_pre<1, AD, -1, false, false, NPRE>(L.dq, L.a, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
+                     tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau, L.wvec, pre);
         // small critic tensors: Wc3, bc2 (column owners), bc3 (one thread)
         {
             const int NT = (HC + 15) >> 4;
@@ -315,7 +345,11 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
 
         // ================= step 4: actor forward with the updated trunk (DDPG.py:90) =================
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1o, (const lds_f32*)(L.w1o + S * H1), L.x);
+#else
         u.trunk(th + d.oW1, th + d.ob1, L.x);
+#endif
         for (int i = tid; i < AD * 256; i += kThreads) {
             const int j = i / 256, n = i % 256;
             L.wvec[i] = n < HA ? th[d.oWa3 + n * AD + j] : 0.0f;       // Wa3 transposed [j][n]
@@ -326,7 +360,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         u.template bias_relu<0>(acc, th + d.oba2, HA);
         u.template row_dot<false, AD>(acc, HA, [&](int n, int j) { return th[d.oWa3 + n * AD + j]; }, L.part);   // z partials
         u.template store_masks<-2, true>(acc, HA);
-        __syncthreads();
+        lds_barrier();
         STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             L.aout[i] = ao;
             dv.tap_aout[(size_t)agent * RLC_MAX_BATCH * AD + i] = ao;
         }
-        __syncthreads();
+        lds_barrier();
         STAMP();
         // the h2 accumulators are needed again for dWa3 once dz is known: park them in registers
         f32x4 h2acc[MT][NTW];
@@ -351,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         // dqda[b][j] = sum_n step(g2[b][n]) * Wc3[n] * Wc2[H1+j][n]
         u.template row_dot<true, AD>(acc, HC, [&](int n, int j) { return th[d.oWc2 + rlc_blk_index(d.arow0 + j, n, HC)] * th[d.oWc3 + n]; },
                                      L.part);
-        __syncthreads();
+        lds_barrier();
         STAMP();
         for (int i = tid; i < B * AD; i += kThreads) {
             const int b = i / AD, j = i % AD;
@@ -360,7 +394,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             const float mu = L.mu[i];
             L.dz[i] = -dqda * (1.0f - mu * mu);                         // grad_ys = -dQ/da on tanh output (Q3)
         }
-        __syncthreads();
+        lds_barrier();
         STAMP();
 
         // ================= step 6: actor step =================
@@ -398,15 +432,15 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         }
         const float alpha_a = adam_alpha(lr_a, pw[0], pw[1]);
         u.template bwd_gemm<AD, -2>(acc, th + d.oWa2, HA, H1, L.dz, L.wvec);
-        __syncthreads();
+        lds_barrier();
         STAMP();
-#ifndef RLC_NO_EARLY_PREFETCH
+#ifdef RLC_EARLY_PREFETCH
         u.template wgrad_prefetch<false, 1>(pre, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, tt + d.oWa2);
 #endif
         u.trunk_grad_adam(acc, th, m_a, v_a, alpha_a, d.oW1, d.ob1, tap_ga, tt, tau, L.x);
         STAMP();
-        u.template wgrad_adam<AD, 0>(L.dz, nullptr, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
-                     tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau, L.wvec, prep);
+        u.template wgrad_adam_pre<AD, 0, -1, false, false, NPRE>(L.dz, nullptr, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, alpha_a,
+                     tap_ga ? tap_ga + d.oWa2 : nullptr, tt + d.oWa2, tau, L.wvec, pre);
         {
             const int NT = (HA + 15) >> 4;
 #pragma unroll

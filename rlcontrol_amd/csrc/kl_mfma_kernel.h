@@ -103,6 +103,12 @@ struct KSmem {
 };
 
 __host__ __device__ inline int kl_mfma_ldh(const RlcSacDims& d) { return ldh_for(d.L1A > d.L1C ? d.L1A : d.L1C); }
+__host__ __device__ constexpr bool kl_z1s_in_global(int MT) { return MT > 2; }
+// floats of the agent's scratch row the MFMA kernel uses: Q at the B x K nodes, then (more than two batch tiles) z1s
+__host__ __device__ inline size_t kl_mfma_scratch_floats(const RlcSacDims& d, int nodes, int MT) {
+    const size_t rows = ((size_t)d.B * (size_t)nodes + 63) & ~(size_t)63;
+    return rows + (kl_z1s_in_global(MT) ? (size_t)MT * 16 * kl_mfma_ldh(d) : 0);
+}
 
 __host__ __device__ inline size_t ksmem_carve(const RlcSacDims& d, int MT, int MTQ, lds_u8* base, KSmem* out) {
     size_t off = 0;
@@ -122,7 +128,9 @@ __host__ __device__ inline size_t ksmem_carve(const RlcSacDims& d, int MT, int M
     L.wvec = (lds_f32*)take(sizeof(float) * 2 * 256);
     lds_f32** ps[] = {&L.x, &L.x2, &L.xq, &L.xn};
     for (auto p : ps) *p = (lds_f32*)take(sizeof(float) * MB * SMAX);
-    L.z1s = (lds_f32*)take(sizeof(float) * MB * LDH);
+    // at more than two batch tiles the first-layer image of Q (MB x LDH floats: 90 KB at seven tiles) lives in the agent's
+    // global scratch instead (kl_z1s_in_global): the node passes read two or three of its rows each, L1-resident
+    L.z1s = kl_z1s_in_global(MT) ? nullptr : (lds_f32*)take(sizeof(float) * MB * LDH);
     L.w1a = (lds_f32*)take(sizeof(float) * 256);
     lds_f32** pn[] = {&L.node_a, &L.node_w, &L.node_u, &L.node_j};
     for (auto p : pn) *p = (lds_f32*)take(sizeof(float) * KL_MAXNODES);
@@ -197,6 +205,9 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
     const bool integral = dv.kl_optim == RLC_KL_OPTIM_INTG || dv.kl_optim == RLC_KL_OPTIM_HARD_INTG;
     const int rows = B * K;
     float* iq = dv.scratch + (size_t)agent * dv.scratch_stride;            // [rows] Q at the nodes
+    constexpr bool ZG = kl_z1s_in_global(MT);
+    static_assert(!(ZG && SPLIT), "latency mode keeps the first-layer image in LDS (two batch tiles)");
+    float* z1g = iq + (((size_t)rows + 63) & ~(size_t)63);                  // ZG: [MB][LDH] first-layer image of Q
     const float LOG_SQRT_2PI = 0.9189385332046727f, EPS = 1e-6f;
     const float invB = 1.0f / (float)B;
 
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
         L.r[i] = 0.f; L.g[i] = 0.f; L.vt[i] = 0.f; L.q[i] = 0.f; L.qn[i] = 0.f; L.v[i] = 0.f; L.dq[i] = 0.f; L.dvs[i] = 0.f;
     }
     for (int i = tid; i < MB * NS; i += kThreads) L.dml[i] = 0.f;
-    for (int i = tid; i < MB * LDH; i += kThreads) L.z1s[i] = 0.f;
+    if constexpr (!ZG) for (int i = tid; i < MB * LDH; i += kThreads) L.z1s[i] = 0.f;
     for (int i = tid; i < MB * KL_MSTRIDE / 4; i += kThreads) reinterpret_cast<lds_u32*>(L.mask)[i] = 0u;
     for (int k = tid; k < KL_MAXNODES; k += kThreads) {
         const bool live = k < K;
@@ -236,7 +247,9 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
                     f32x4 o = {0.f, 0.f, 0.f, 0.f};
                     if (i < nr) {
                         const int rho = p0 + i, b = rho / K, k = rho - b * K;
-                        const f32x4 zz = *reinterpret_cast<const lds_f32x4*>(&L.z1s[b * LDH + (cq << 2)]);
+                        f32x4 zz;
+                        if constexpr (ZG) zz = *reinterpret_cast<const f32x4*>(&z1g[b * LDH + (cq << 2)]);
+                        else zz = *reinterpret_cast<const lds_f32x4*>(&L.z1s[b * LDH + (cq << 2)]);
                         const float ak = L.node_a[k];
 #pragma unroll
                         for (int e = 0; e < 4; e++) o[e] = fmaxf(zz[e] + ak * wa[e], 0.0f);
@@ -262,8 +275,9 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
             float* zb = sp.zbuf + (size_t)rel_agent * MB * LDH;
             for (int upd = 0; upd < n_updates; upd++) {
                 if (!kl_group_barrier(sp.bar + rel_agent, sp.C, bar_gen, sp.err, L.dups + 3)) return;
-                for (int i = tid; i < (MB * LDH) >> 2; i += kThreads)
-                    reinterpret_cast<lds_f32x4*>(L.z1s)[i] = reinterpret_cast<const f32x4*>(zb)[i];
+                if constexpr (!ZG)
+                    for (int i = tid; i < (MB * LDH) >> 2; i += kThreads)
+                        reinterpret_cast<lds_f32x4*>(L.z1s)[i] = reinterpret_cast<const f32x4*>(zb)[i];
                 for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;
                 __syncthreads();
                 node_passes();
@@ -453,7 +467,8 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_mfma_kernel(RlcSacDev 
                     for (int i = 0; i < S; i++)
                         o += L.x[b * SMAX + i] * *reinterpret_cast<const f32x4*>(&th[d.qW1 + i * L1C + n0]);
                 }
-                *reinterpret_cast<lds_f32x4*>(&L.z1s[b * LDH + n0]) = o;
+                if constexpr (ZG) *reinterpret_cast<f32x4*>(&z1g[b * LDH + n0]) = o;      // visible after the __syncthreads below
+                else *reinterpret_cast<lds_f32x4*>(&L.z1s[b * LDH + n0]) = o;
                 if constexpr (SPLIT) *reinterpret_cast<f32x4*>(&sp.zbuf[(size_t)rel_agent * MB * LDH + b * LDH + n0]) = o;
             }
             for (int n = tid; n < 256; n += kThreads) L.w1a[n] = n < L1C ? th[d.qW1 + S * L1C + n] : 0.0f;

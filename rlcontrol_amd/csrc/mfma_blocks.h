@@ -71,6 +71,21 @@ __device__ __forceinline__ void stagger_start() {
     }
 }
 
+// Workgroup barrier for phase boundaries that hand over LDS data only.  __syncthreads() also waits for every outstanding
+// global-memory operation of the wave (s_waitcnt vmcnt(0)): after a phase that stored taps or Adam state, that is a
+// store round trip to HBM on the critical path.  lds_barrier() waits for the wave's LDS / scalar traffic only; global
+// stores keep draining behind it.  Use it only where no wave reads, after the barrier, global data that another wave
+// wrote since the last __syncthreads() (each kernel keeps full barriers at those points).
+// Measured (profiles/r03_variant_timings_s5.txt): no difference on any of the three kernels -- the store round trips are
+// not on the critical path -- so the default stays __syncthreads(); -DRLC_LDS_BARRIERS enables the relaxed form.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef RLC_LDS_BARRIERS
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
+
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;     // two waves per SIMD: one can issue MFMA while the other does VALU / waits on loads
 constexpr int SMAX = 8;       // state rows are padded to 8 floats in LDS (two ds_read_b128)
@@ -235,13 +250,39 @@ struct Blk {
     // ---------------------------------------------------------------------------------------
     // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
     // ---------------------------------------------------------------------------------------
-    __device__ __forceinline__ void trunk(const float* W1, const float* b1, const lds_f32* xs) {
+    // WP: const float* (the blob in global memory) or const lds_f32* (a copy staged in LDS: stage_load / stage_store)
+    template <class WP>
+    __device__ __forceinline__ void trunk(WP W1, WP b1, const lds_f32* xs) {
         if constexpr (ablate(3)) return;
         if (S <= 4) trunk_t<4>(W1, b1, xs);      // wave-uniform: Pendulum-sized states need one 16-byte read per row
         else trunk_t<SMAX>(W1, b1, xs);
     }
-    template <int SP>
-    __device__ __forceinline__ void trunk_t(const float* W1, const float* b1, const lds_f32* xs) {
+    // First-layer weights staged in LDS (opt-in, -DRLC_W1_STAGE: measured -0.6 % on DDPG, -1.4 % on SoftActorCritic,
+    // profiles/r03_variant_timings_s6.txt -- the dependent load was not what the passes wait for).  The first layer ([S][H1] + bias, a few KB) is re-read from global memory by
+    // every first-layer pass -- a dependent global load (L2 or HBM latency) in front of a microsecond of arithmetic,
+    // several times per update.  Staged once per update instead: the loads are issued before the minibatch is sampled
+    // and gathered (stage_load: kStage registers per set), stored to LDS behind it (stage_store), and the passes read
+    // [S][H1] weights then [H1] biases from there; a first-layer Adam step that a later pass must see writes its new
+    // values into the LDS copy as well (trunk_grad_adam's `stage` argument).
+    static constexpr int kStage = ((SMAX + 1) * 256 + kThreads - 1) / kThreads;
+    __device__ __forceinline__ void stage_load(float (&r)[kStage], const float* W1, const float* b1) const {
+        const int nw = S * H1, n = nw + H1;
+#pragma unroll
+        for (int j = 0; j < kStage; j++) {
+            const int i = tid + kThreads * j;
+            r[j] = i < nw ? W1[i] : (i < n ? b1[i - nw] : 0.0f);
+        }
+    }
+    __device__ __forceinline__ void stage_store(const float (&r)[kStage], lds_f32* ws) const {
+        const int n = (S + 1) * H1;
+#pragma unroll
+        for (int j = 0; j < kStage; j++) {
+            const int i = tid + kThreads * j;
+            if (i < n) ws[i] = r[j];
+        }
+    }
+    template <int SP, class WP>
+    __device__ __forceinline__ void trunk_t(WP W1, WP b1, const lds_f32* xs) {
         // lane = a quad of 4 adjacent columns (its S x 4 weights and 4 biases stay in registers), wave w = rows
         // w, w+8, ...: per row one broadcast read of the state and ONE 16-byte store of four activations
         // (a quarter of the LDS store instructions of the one-column-per-thread form; same i-order per element)
@@ -596,6 +637,38 @@ struct Blk {
     __device__ __forceinline__ void store_masks(const f32x4 (&acc)[MT][NTW], int N) {
         if constexpr (ablate(9)) return;
         const int NT = (N + 15) >> 4;
+#ifdef RLC_PACKED_MASKS
+        // (opt-in: measured +-0 on DDPG, -1.4 % on SoftActorCritic, profiles/r03_variant_timings_s6.txt)
+        // One dword store per lane and tile instead of four byte stores (which land four to a bank).  A lane holds the
+        // flags of rows 4g..4g+3 at unit c; a mask dword is four units of one row: the four lanes of a quad (units
+        // 4q..4q+3, same rows) transpose their 4 x 4 bytes with quad-broadcast DPP moves and byte permutes, and lane j of
+        // the quad stores row 4g + j.  (Row stride 4 * odd dwords: the 64 stores of an instruction hit 64 banks.)
+        constexpr unsigned code = BIT == -2 ? 0x38u : 1u << (BIT < 0 ? 0 : BIT);
+        const int r0 = c & 3;
+        const unsigned sel = (unsigned)r0 | ((unsigned)(4 + r0) << 8) | 0x0c0c0000u;     // bytes: lo[r0], hi[r0], 0, 0
+#pragma unroll
+        for (int i = 0; i < NTW; i++) {
+            const int t = tile_of(i);
+            if (t < NT) {
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    unsigned w = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) w |= acc[mt][i][r] > 0.0f ? code << (8 * r) : 0u;
+                    const unsigned w0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x00, 0xf, 0xf, false);
+                    const unsigned w1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x55, 0xf, 0xf, false);
+                    const unsigned w2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xaa, 0xf, 0xf, false);
+                    const unsigned w3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0xff, 0xf, 0xf, false);
+                    const unsigned lo = __builtin_amdgcn_perm(w1, w0, sel), hi = __builtin_amdgcn_perm(w3, w2, sel);
+                    const unsigned out = lo | (hi << 16);
+                    lds_u32* p = reinterpret_cast<lds_u32*>(&L.mask[(16 * mt + 4 * g + r0) * MSTRIDE + 16 * t + (c & 12)]);
+                    if (OVERWRITE) *p = out;
+                    else *p = (*p & ~(0x01010101u * code)) | out;
+                }
+            }
+        }
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
             const int t = tile_of(i);
@@ -866,18 +939,19 @@ struct Blk {
     // (LDS [MB][SMAX]).  extra(b, k): further contributions to dL/dh1[b][k] (heads that hang off the first layer).
     // GONLY: only the gradient is produced (written to `tap`, which must not be null); no Adam, no Polyak -- the
     // batch-split kernel (ddpg_split_kernel.h) reduces such partial gradients over the CUs of an agent first.
+    // stage (or null): the LDS copy of this first layer (stage_store layout) that receives the stepped values too
     template <class EXTRA = NoExtra, bool GONLY = false>
     __device__ __forceinline__ void trunk_grad_adam(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
                                                     float alpha, int oW1, int ob1, float* tap, float* tt, float tau,
-                                                    const lds_f32* xs, EXTRA extra = EXTRA{}) {
+                                                    const lds_f32* xs, EXTRA extra = EXTRA{}, lds_f32* stage = nullptr) {
         if constexpr (ablate(7)) return;
-        if (S <= 4) trunk_grad_adam_t<4, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);     // wave-uniform
-        else trunk_grad_adam_t<SMAX, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra);
+        if (S <= 4) trunk_grad_adam_t<4, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra, stage);     // wave-uniform
+        else trunk_grad_adam_t<SMAX, EXTRA, GONLY>(acc, th, m, v, alpha, oW1, ob1, tap, tt, tau, xs, extra, stage);
     }
     template <int SP, class EXTRA, bool GONLY = false>
     __device__ __forceinline__ void trunk_grad_adam_t(const f32x4 (&acc)[MT][NTW], float* th, float* m, float* v,
                                                       float alpha, int oW1, int ob1, float* tap, float* tt, float tau,
-                                                      const lds_f32* xs, EXTRA extra) {
+                                                      const lds_f32* xs, EXTRA extra, lds_f32* stage) {
         const int NT = (H1 + 15) >> 4;
 #pragma unroll
         for (int i = 0; i < NTW; i++) {
@@ -928,6 +1002,7 @@ struct Blk {
                         float mm = m[p], vv = v[p];
                         const float nv = astep_small(th[p], gr, mm, vv, alpha);
                         m[p] = mm; v[p] = vv; th[p] = nv;
+                        if (stage) stage[is_bias ? S * H1 + k : s * H1 + k] = nv;
                         if (tap) tap[p] = gr;
                         if (tt) tt[p] = polyak(tt[p], nv, tau);
                     }
@@ -953,7 +1028,7 @@ struct Blk {
     // the first two items of this wave (idx = wave, wave + 8) in flight before wgrad_adam is entered: wgrad_prefetch
     // issues them ahead of the backward GEMM that precedes the weight-gradient phase, so that their HBM latency hides
     // under that GEMM instead of under one k-loop (a wave has only two items per matrix at widths <= 128)
-    struct WgPre2 { WgPre a, b; int n; };      // n: how many of the two are in flight (1: only a)
+    struct WgPre2 { WgPre a, b; };
 
     // item idx of a [H1 x N] matrix -> N tile t, first M' tile m0, tiles in the chunk nq
     __device__ __forceinline__ void wg_item_geom(int idx, int N, int& t, int& m0, int& nq) const {
@@ -994,7 +1069,6 @@ struct Blk {
     template <bool NOPOL = false, int NPRE = 2>
     __device__ __forceinline__ void wgrad_prefetch(WgPre2& pre, int N, const float* Wp, const float* mp, const float* vp,
                                                    const float* Wt) const {
-        pre.n = NPRE;
         if constexpr (ablate(0) || ablate(1)) return;
         const int nitems = wg_nitems(N);
         asm volatile("" ::: "memory");
@@ -1010,7 +1084,16 @@ struct Blk {
     __device__ __forceinline__ void wgrad_adam(const lds_f32* seed /* LDS [MB][NS] */, const lds_f32* E /* LDS [MB][NE] or null */,
                                                int N, float* Wp, float* mp, float* vp,
                                                float alpha, float* tapp, float* Wt, float tau,
-                                               const lds_f32* wvec /* LDS [NS][256] */, const WgPre2* pre = nullptr) {
+                                               const lds_f32* wvec /* LDS [NS][256] */) {
+        WgPre2 none;
+        wgrad_adam_pre<NS, NE, BIT, GONLY, NOPOL, 0>(seed, E, N, Wp, mp, vp, alpha, tapp, Wt, tau, wvec, none);
+    }
+    // NPRE > 0: `pre` holds this wave's first NPRE items already in flight (wgrad_prefetch<NOPOL, NPRE>); by reference and
+    // a compile-time count, so that the registers stay registers
+    template <int NS, int NE, int BIT, bool GONLY, bool NOPOL, int NPRE>
+    __device__ __forceinline__ void wgrad_adam_pre(const lds_f32* seed, const lds_f32* E, int N, float* Wp, float* mp, float* vp,
+                                                   float alpha, float* tapp, float* Wt, float tau, const lds_f32* wvec,
+                                                   WgPre2& pre) {
         if constexpr (ablate(0)) return;
         const int NT = (N + 15) >> 4;
         const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the hbuf units; extra rows below
@@ -1166,12 +1249,12 @@ struct Blk {
 #define RLC_CBAR() asm volatile("" ::: "memory")
         RLC_CBAR();
         bool first = true;
-        if (pre) { PA = pre->a; if (pre->n > 1) PB = pre->b; }          // already in flight (wgrad_prefetch)
+        if constexpr (NPRE > 0) { PA = pre.a; if constexpr (NPRE > 1) PB = pre.b; }      // already in flight (wgrad_prefetch)
         else if (idx < nitems) issue(PA, idx);
         sub_stamp(21);
         while (idx < nitems) {
             RLC_CBAR();
-            if (idx + kWaves < nitems && !(pre && first && pre->n > 1)) issue(PB, idx + kWaves);
+            if (idx + kWaves < nitems && !(NPRE > 1 && first)) issue(PB, idx + kWaves);
             first = false;
             RLC_CBAR();
             run_any(PA, idx);

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
             for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + upd) * B + b];
         }
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < B; b += kThreads) {
             const float *ps, *pa, *ps2;
             if (source == RLC_SRC_STAGING) {
@@ -166,15 +166,15 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
 #pragma unroll
             for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
         }
-        __syncthreads();
+        lds_barrier();
 
         // ================= 1: target V'(s') and the float64 TD glue (agents/NAF.py:70) =================
         u.trunk(tt + d.W1, tt + d.b1, L.x2);
-        __syncthreads();
+        lds_barrier();
         u.fwd_gemm(acc, tt + d.Wv2, L2, L1);
         u.template bias_relu<0>(acc, tt + d.bv2, L2);
         u.template row_dot<false, 1>(acc, L2, [&](int n, int) { return tt[d.Wv3 + n]; }, L.part_v);
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < B; b += kThreads) {
             const float vt = u.template part_sum<1>(L.part_v, b, 0) + tt[d.bv3];
             const float y = (float)(L.r[b] + L.g[b] * (double)vt);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             naf_head_ref(d, j, ow, st, ob);
             L.wh[i] = k < L1 ? th[ow + k * st] : 0.0f;
         }
-        __syncthreads();
+        lds_barrier();
         // L heads from the trunk image: wave w < MT takes batch tile w; lane (c, g) sums k = 16 ch + 4 g .. + 3 of row
         // 16 w + c; the four lane groups are combined in a fixed order
         if (u.wave < MT) {
@@ -226,12 +226,12 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         u.template bias_relu<0>(acca, th + d.ba2, L2);
         u.template row_dot<false, AD>(acca, L2, [&](int n, int j) { return L.wvec[j * 256 + n]; }, L.part_a);
         u.template store_masks<0, true>(acca, L2);
-        if (u.split_mode((L2 + 15) >> 4)) __syncthreads();      // the split tile's hand-off buffer is reused
+        if (u.split_mode((L2 + 15) >> 4)) lds_barrier();      // the split tile's hand-off buffer is reused
         u.fwd_gemm(acc, th + d.Wv2, L2, L1);
         u.template bias_relu<0>(acc, th + d.bv2, L2);
         u.template row_dot<false, 1>(acc, L2, [&](int n, int) { return wv3[n]; }, L.part_v);
         u.template store_masks<1, false>(acc, L2);
-        __syncthreads();
+        lds_barrier();
         // ================= 3: per sample: L columns, advantage, Q, and the seeds of every head's gradient =================
         for (int b = tid; b < B; b += kThreads) {
             float diff[AD], ddiff[AD], tanhv[AD];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
 #pragma unroll
             for (int j = 0; j < AD; j++) L.dz[b * AD + j] = -ddiff[j] * amax[j] * (1.0f - tanhv[j] * tanhv[j]);
         }
-        __syncthreads();
+        lds_barrier();
         // ================= 4: output-layer / bias gradients from the live accumulators =================
         float g_wa3[NTW][AD], g_ba2[NTW], g_wv3[NTW], g_bv2[NTW];
         {
@@ -324,15 +324,16 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         // ================= 5: d trunk = V branch (rank one) + mu branch (accumulated) + heads =================
         const float alpha = adam_alpha(dv.lr[agent], pw[0], pw[1]);
         u.template bwd_gemm<1, 1, false>(acc, th + d.Wv2, L2, L1, L.dV, wv3);
-        if (u.split_mode((L1 + 15) >> 4)) __syncthreads();      // the split tile's hand-off buffer is reused
+        if (u.split_mode((L1 + 15) >> 4)) lds_barrier();      // the split tile's hand-off buffer is reused
         u.template bwd_gemm<AD, 0, true>(acc, th + d.Wa2, L2, L1, L.dz, L.wvec);
-        __syncthreads();
+        lds_barrier();
         // the first weight-gradient item's W / m / v / W' go in flight before the first-layer and head gradients
         typename U::WgPre2 pre;
-        const typename U::WgPre2* prep = nullptr;
-#ifndef RLC_NO_EARLY_PREFETCH
+#ifdef RLC_EARLY_PREFETCH
+        constexpr int NPRE = 1;
         u.template wgrad_prefetch<false, 1>(pre, L2, th + d.Wa2, mm + d.Wa2, vv + d.Wa2, tt + d.Wa2);
-        prep = &pre;
+#else
+        constexpr int NPRE = 0;
 #endif
         u.trunk_grad_adam(acc, th, mm, vv, alpha, d.W1, d.b1, tapg, tt, tau, L.x, [&](int b, int k) {
             const f32x4 dh = *reinterpret_cast<const lds_f32x4*>(&L.dhd[b * NHP]);
@@ -372,8 +373,8 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             }
         }
         // ================= 6: the two L1 x L2 matrices, Adam + Polyak in the GEMM epilogues =================
-        u.template wgrad_adam<AD, 0, 0>(L.dz, nullptr, L2, th + d.Wa2, mm + d.Wa2, vv + d.Wa2, alpha,
-                                        tapg ? tapg + d.Wa2 : nullptr, tt + d.Wa2, tau, L.wvec, prep);
+        u.template wgrad_adam_pre<AD, 0, 0, false, false, NPRE>(L.dz, nullptr, L2, th + d.Wa2, mm + d.Wa2, vv + d.Wa2, alpha,
+                                        tapg ? tapg + d.Wa2 : nullptr, tt + d.Wa2, tau, L.wvec, pre);
         u.template wgrad_adam<1, 0, 1>(L.dV, nullptr, L2, th + d.Wv2, mm + d.Wv2, vv + d.Wv2, alpha,
                                        tapg ? tapg + d.Wv2 : nullptr, tt + d.Wv2, tau, wv3);
         {

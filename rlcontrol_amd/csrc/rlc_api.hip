@@ -134,6 +134,8 @@ int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, 
     h->io_dev = nullptr; h->io_cap = 0;
     h->io_host = nullptr; h->io_host_cap = 0;
     h->aq_dev = nullptr; h->aq_host = nullptr; h->aq_cap = 0; h->aq_first = 0; h->aq_n = 0;
+    h->aq_seq = 0; h->aq_flagged = false;
+    h->idx_pin = nullptr; h->idx_pin_cap = 0; h->idx_ev = nullptr; h->idx_ev_armed = false;
     h->io_pending = false;
     h->variant = 0;
     h->split_c = 1; h->split_part = nullptr; h->split_bar = nullptr; h->split_err = nullptr;
@@ -183,6 +185,8 @@ void rlc_h_destroy(rlc_handle* h) {
     if (h->io_host) (void)hipHostFree(h->io_host);
     if (h->aq_dev) (void)hipFree(h->aq_dev);
     if (h->aq_host) (void)hipHostFree(h->aq_host);
+    if (h->idx_pin) (void)hipHostFree(h->idx_pin);
+    if (h->idx_ev) (void)hipEventDestroy(h->idx_ev);
     if (h->st) {
         (void)hipEventDestroy(h->ev0);
         (void)hipEventDestroy(h->ev1);
@@ -529,23 +533,27 @@ int rlc_ddpg_act_queue(rlc_handle* h, int32_t first_agent, int32_t n, const doub
     RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->dv.n_agents, "agent range [%d,%d) invalid",
                 first_agent, first_agent + n);
     RLC_REQUIRE(states, "null array");
-    const size_t S = h->dv.d.S, A = h->dv.d.A, need = sizeof(float) * n * (S + A);
+    // Zero-copy: the acting kernel reads the states from, and stores the actions (and, for one agent, a completion word)
+    // into, pinned host memory -- no copy operations on the stream, one kernel launch.
+    const size_t S = h->dv.d.S, A = h->dv.d.A, need = sizeof(float) * (n * (S + A) + 4);
     if (need > h->aq_cap) {
         RLC_HIP(hipStreamSynchronize(h->st));
-        if (h->aq_dev) RLC_HIP(hipFree(h->aq_dev));
         if (h->aq_host) RLC_HIP(hipHostFree(h->aq_host));
-        h->aq_dev = nullptr; h->aq_host = nullptr; h->aq_cap = 0;
-        RLC_HIP(hipMalloc((void**)&h->aq_dev, need * 2));
+        h->aq_host = nullptr; h->aq_cap = 0;
         RLC_HIP(hipHostMalloc((void**)&h->aq_host, need * 2, hipHostMallocDefault));
         h->aq_cap = need * 2;
+        memset(h->aq_host, 0, h->aq_cap);
     } else if (h->aq_n) {
-        RLC_HIP(hipStreamSynchronize(h->st));     // a queued forward nobody fetched still reads / writes the buffers
+        RLC_HIP(hipStreamSynchronize(h->st));     // a queued forward nobody fetched still reads / writes the buffer
     }
     h->aq_n = 0;
     for (size_t i = 0; i < (size_t)n * S; i++) h->aq_host[i] = (float)states[i];
-    RLC_HIP(hipMemcpyAsync(h->aq_dev, h->aq_host, sizeof(float) * n * S, hipMemcpyHostToDevice, h->st));
-    if (rlc_launch_act(h->dv, first_agent, n, h->aq_dev, h->aq_dev + n * S, 0, h->st)) return 1;
-    RLC_HIP(hipMemcpyAsync(h->aq_host + n * S, h->aq_dev + n * S, sizeof(float) * n * A, hipMemcpyDeviceToHost, h->st));
+    int* flag = (int*)(h->aq_host + h->aq_cap / sizeof(float) - 1);
+    h->aq_flagged = n == 1;
+    if (h->aq_flagged) h->aq_seq += 1;
+    if (rlc_launch_act(h->dv, first_agent, n, h->aq_host, h->aq_host + n * S, 0, h->st, h->aq_flagged ? flag : nullptr,
+                       h->aq_seq))
+        return 1;
     h->aq_first = first_agent; h->aq_n = n;
     return 0;
 }
@@ -557,7 +565,20 @@ int rlc_ddpg_act_fetch(rlc_handle* h, int32_t first_agent, int32_t n, float* out
     RLC_REQUIRE(h->aq_n > 0, "no acting forward is queued (rlc_ddpg_act_queue)");
     RLC_REQUIRE(first_agent == h->aq_first && n == h->aq_n, "queued forward is for agents [%d,%d), asked for [%d,%d)",
                 h->aq_first, h->aq_first + h->aq_n, first_agent, first_agent + n);
-    RLC_HIP(hipStreamSynchronize(h->st));
+    bool done = false;
+    if (h->aq_flagged) {
+        // spin on the completion word the kernel stores after its actions (microseconds after the kernel ends; a stream
+        // synchronisation wakes up tens of microseconds later); bounded, then the ordinary wait
+        volatile int* flag = (volatile int*)(h->aq_host + h->aq_cap / sizeof(float) - 1);
+        for (long spin = 0; spin < 200000000L; spin++) {
+            if (*flag == h->aq_seq) { done = true; break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!done) RLC_HIP(hipStreamSynchronize(h->st));
     memcpy(out_actions, h->aq_host + (size_t)n * h->dv.d.S, sizeof(float) * n * h->dv.d.A);
     h->aq_n = 0;
     return 0;
@@ -681,9 +702,24 @@ int rlc_ddpg_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indice
                 RLC_REQUIRE(p[i] >= 0 && p[i] < size, "agent %d: sample index %lld out of range (size %lld)", a,
                             (long long)p[i], size);
         }
+        source = RLC_SRC_REPLAY_HOST_INDICES;
+        if (count <= 1024) {
+            // the step loop of a drop-in agent (one agent, one update): the kernel reads the indices straight from pinned
+            // host memory -- no copy operation on the stream; an event guards the buffer against the next call
+            if (!h->idx_pin) {
+                RLC_HIP(hipHostMalloc((void**)&h->idx_pin, sizeof(long long) * 1024, hipHostMallocDefault));
+                h->idx_pin_cap = 1024;
+                RLC_HIP(hipEventCreateWithFlags(&h->idx_ev, hipEventDisableTiming));
+            }
+            if (h->idx_ev_armed) RLC_HIP(hipEventSynchronize(h->idx_ev));
+            memcpy(h->idx_pin, host_indices, sizeof(long long) * count);
+            const int rc = launch_update(h, 0, NA, n_updates, source, h->idx_pin);
+            RLC_HIP(hipEventRecord(h->idx_ev, h->st));
+            h->idx_ev_armed = true;
+            return rc;
+        }
         if (rlc_h_ensure_idx(h, count)) return 1;
         RLC_HIP(hipMemcpyAsync(h->idx_dev, host_indices, sizeof(long long) * count, hipMemcpyHostToDevice, h->st));
-        source = RLC_SRC_REPLAY_HOST_INDICES;
     }
     return launch_update(h, 0, NA, n_updates, source, h->idx_dev);
 }

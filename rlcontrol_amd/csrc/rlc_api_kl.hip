@@ -3,6 +3,7 @@
 // the handle reuses the device view RlcSacDev (with the Q network's action rows at the INPUT layer: RlcSacDims::qcat)
 // and the blob / act / update / tap bodies of rlc_api_sac.hip; what is particular to them -- the action-integral
 // update kernel, torch's Adam bookkeeping, the quadrature nodes -- lives here and in kl_generic.hip.
+#include <algorithm>
 #include <string.h>
 
 #include <vector>
@@ -82,7 +83,11 @@ int rlc_kl_create(const rlc_kl_config* cfg, rlc_handle** out) {
     TRY(rlc_h_malloc(h, &dv.tap_loss, NA * 4));
     TRY(rlc_h_malloc(h, &dv.kl_tap_iq, NA * (size_t)cfg->batch_size * K));
     dv.tap_g = nullptr;
-    dv.scratch_stride = (long long)((rlc_kl_scratch_floats(dv.d, dv.kl_nodes) + 63) & ~(size_t)63);
+    {
+        size_t need = rlc_kl_scratch_floats(dv.d, dv.kl_nodes);
+        if (rlc_kl_mfma_supported(dv.d, dv.kl_nodes)) need = std::max(need, rlc_kl_mfma_scratch_floats(dv.d, dv.kl_nodes));
+        dv.scratch_stride = (long long)((need + 63) & ~(size_t)63);
+    }
     TRY(rlc_h_malloc(h, &dv.scratch, NA * (size_t)dv.scratch_stride, false));
 #undef TRY
     hipError_t e = hipMemcpyAsync(lp, cfg->pi_lr, NA * sizeof(float), hipMemcpyHostToDevice, h->st);

@@ -281,7 +281,7 @@ int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents,
 
 // acting / evaluation
 int rlc_launch_act(const RlcDev& dv, int first_agent, int n, const float* states_dev, float* out_dev, int explore,
-                   hipStream_t st);
+                   hipStream_t st, int* done_flag = nullptr, int done_val = 0);
 int rlc_launch_qval(const RlcDev& dv, int agent, int n, const float* states_dev, const float* actions_dev,
                     float* out_dev, hipStream_t st);
 int rlc_launch_reset_noise(const RlcDev& dv, int first_agent, int n, hipStream_t st);

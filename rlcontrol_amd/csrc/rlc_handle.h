@@ -24,6 +24,10 @@ struct rlc_handle {
     // queued acting forward (rlc_ddpg_act_queue / rlc_ddpg_act_fetch): buffers of their own, nothing else writes them
     float* aq_dev; float* aq_host; size_t aq_cap;   // device / pinned host staging: [n][S] states then [n][A] actions
     int aq_first, aq_n;                  // agent range of the queued forward; aq_n == 0: nothing queued
+    int aq_seq;                          // completion flag protocol of one-agent forwards: the kernel stores ++aq_seq
+    bool aq_flagged;                     // the queued forward reports through the flag word (aq_host[aq_cap / 4 - 1])
+    long long* idx_pin; size_t idx_pin_cap;   // pinned, device-readable index staging for small host-index updates
+    hipEvent_t idx_ev; bool idx_ev_armed;     // recorded behind the launch that reads idx_pin
     // ---- DDPG
     RlcDev dv;
     int variant;                         // requested kernel: 0 auto, 1 generic, 2 mfma

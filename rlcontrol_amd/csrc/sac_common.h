@@ -103,6 +103,7 @@ int rlc_launch_kl_update(const RlcSacDev& dv, int first_agent, int n_agents, int
                          const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
                          const RlcSacRollout* rollout = nullptr);
 bool rlc_kl_mfma_supported(const RlcSacDims& d, int nodes);
+size_t rlc_kl_mfma_scratch_floats(const RlcSacDims& d, int nodes);   // floats of an agent's scratch row the MFMA kernel needs
 size_t rlc_kl_split_zbuf_floats(const RlcSacDims& d);
 int rlc_kl_split_grid(int n_agents, int C);
 int rlc_launch_kl_update_mfma_split(const RlcSacDev& dv, float* zbuf, unsigned int* bar, int* err, int C, int first_agent,

@@ -48,6 +48,7 @@ struct SSmem {
     lds_i32* pool;
     lds_i32* dups;
     lds_f32* pol;        // scratch of the on-device training step (sac_rollout_device.h)
+    lds_f32 *w1vt, *w1q, *w1p, *w1v;     // first layers staged in LDS: vf target, qf, pi, vf (mfma_blocks.h stage_*)
 };
 
 __host__ __device__ inline int sac_mfma_ldh(const RlcSacDims& d) { return ldh_for(d.L1A > d.L1C ? d.L1A : d.L1C); }
@@ -80,6 +81,14 @@ __host__ __device__ inline size_t ssmem_carve(const RlcSacDims& d, int MT, lds_u
     L.pool = (lds_i32*)take(sizeof(int) * 3 * RLC_MAX_BATCH);
     L.dups = (lds_i32*)take(sizeof(int) * 4);
     L.pol = (lds_f32*)take(sizeof(float) * (sac_policy_lds_floats(d) + 4));
+#ifdef RLC_W1_STAGE
+    L.w1vt = (lds_f32*)take(sizeof(float) * (d.S + 1) * d.L1C);
+    L.w1q = (lds_f32*)take(sizeof(float) * (d.S + 1) * d.L1C);
+    L.w1p = (lds_f32*)take(sizeof(float) * (d.S + 1) * d.L1A);
+    L.w1v = (lds_f32*)take(sizeof(float) * (d.S + 1) * d.L1C);
+#else
+    L.w1vt = L.w1q = L.w1p = L.w1v = nullptr;
+#endif
     if (out) *out = L;
     return off;
 }
@@ -87,12 +96,12 @@ __host__ __device__ inline size_t ssmem_carve(const RlcSacDims& d, int MT, lds_u
 // block-wide sum of v over threads (fixed order: deterministic); result broadcast to all threads
 __device__ inline float sac_blk_sum(float v, lds_f32* red) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     float s = 0.0f;
     for (int w = 0; w < kWaves; w++) s += red[w];
-    __syncthreads();
+    lds_barrier();
     return s;
 }
 
@@ -146,6 +155,17 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             // on-device experiment loop: one environment step first; update when learn() would run
             if (!rlc_sac_train_step_device(rollout, agent, (float*)L.pol)) continue;
         }
+#ifdef RLC_W1_STAGE
+        // every first-layer pass of this update reads pre-update weights: all four first layers go in flight now and
+        // land in LDS behind the minibatch gather
+        float stg_vt[U::kStage], stg_q[U::kStage], stg_p[U::kStage], stg_v[U::kStage];
+        u.H1 = L1C;
+        u.stage_load(stg_vt, tt + d.vW1, tt + d.vb1);
+        u.stage_load(stg_q, th + d.qW1, th + d.qb1);
+        u.stage_load(stg_v, th + d.vW1, th + d.vb1);
+        u.H1 = L1A;
+        u.stage_load(stg_p, th + d.pW1, th + d.pb1);
+#endif
         // ================= sample + gather (utils/replaybuffer.py:32-37) =================
         const RlcRingMeta ring = dv.rep.ring[agent];
         if (source == RLC_SRC_REPLAY_DEVICE_SAMPLER) {
@@ -156,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         } else if (source == RLC_SRC_REPLAY_HOST_INDICES) {
             for (int b = tid; b < B; b += kThreads) L.idx[b] = host_idx[((size_t)blockIdx.x * n_updates + upd) * B + b];
         }
-        __syncthreads();
+        lds_barrier();
         const unsigned long long nctr = dv.noise_ctr[agent];
         for (int b = tid; b < B; b += kThreads) {
             const float *ps, *pa, *ps2;
@@ -190,37 +210,57 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 L.eps[b * AD + j] = e;
             }
         }
-        __syncthreads();
+#ifdef RLC_W1_STAGE
+        u.H1 = L1C;
+        u.stage_store(stg_vt, L.w1vt);
+        u.stage_store(stg_q, L.w1q);
+        u.stage_store(stg_v, L.w1v);
+        u.H1 = L1A;
+        u.stage_store(stg_p, L.w1p);
+#endif
+        lds_barrier();
         if (tid == 0 && !eps_in) dv.noise_ctr[agent] = nctr + 1;
 
         // ================= 1: V'(s') from the target network (sac_network.py:107) =================
         u.H1 = L1C;
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1vt, (const lds_f32*)(L.w1vt + S * L1C), L.x2c);
+#else
         u.trunk(tt + d.vW1, tt + d.vb1, L.x2c);
-        __syncthreads();
+#endif
+        lds_barrier();
         u.fwd_gemm(acc, tt + d.vW2, L2C, L1C);
         u.template bias_relu<0>(acc, tt + d.vb2, L2C);
         u.template row_dot<false, 1>(acc, L2C, [&](int n, int) { return tt[d.vW3 + n]; }, L.part_q);
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < B; b += kThreads) L.vt[b] = u.template part_sum<1>(L.part_q, b, 0) + tt[d.vb3];
         // ================= 2: the hidden contraction of Q, shared by Q(s,a) and Q(s,pi) =================
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1q, (const lds_f32*)(L.w1q + S * L1C), L.x);
+#else
         u.trunk(th + d.qW1, th + d.qb1, L.x);
-        __syncthreads();
+#endif
+        lds_barrier();
         f32x4 accq[MT][NTW];
         u.fwd_gemm(accq, th + d.qW2, L2C, L1C);
-        __syncthreads();                 // every wave is done reading hbuf = qh1
+        lds_barrier();                 // every wave is done reading hbuf = qh1
         // ================= 3: pi forward (sac_network.py:234-301) =================
         u.H1 = L1A;
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1p, (const lds_f32*)(L.w1p + S * L1A), L.xc);
+#else
         u.trunk(th + d.pW1, th + d.pb1, L.xc);
+#endif
         for (int i = tid; i < NS * 256; i += kThreads) {      // [Wm | Ws] transposed: row j < A -> Wm[:, j], j >= A -> Ws[:, j-A]
             const int j = i / 256, n = i % 256;
             L.wvec[i] = n < L2A ? (j < AD ? th[d.pWm + n * AD + j] : th[d.pWs + n * AD + (j - AD)]) : 0.0f;
         }
-        __syncthreads();
+        lds_barrier();
         u.fwd_gemm(acc, th + d.pW2, L2A, L1A);
         u.template bias_relu<0>(acc, th + d.pb2, L2A);
         u.template row_dot<false, NS>(acc, L2A, [&](int n, int j) { return L.wvec[j * 256 + n]; }, L.part_h);
         u.template store_masks<0, true>(acc, L2A);
-        __syncthreads();
+        lds_barrier();
         for (int b = tid; b < B; b += kThreads) {
             float lp = 0.0f;
 #pragma unroll
@@ -245,13 +285,13 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             L.logp[b] = lp;
             dv.tap_logp[(size_t)agent * RLC_MAX_BATCH + b] = lp;
         }
-        __syncthreads();
+        lds_barrier();
         // ================= 4: Q(s,pi), dQ/da, Q(s,a) from the parked contraction =================
         u.template concat_head_dots<AD>(accq, th + d.qb2, L2C, L.api, th + d.qW2, d.arow0, th + d.qW3, L.part_p);
         u.template bias_relu<AD>(accq, th + d.qb2, L2C, L.a, th + d.qW2, d.arow0);
         u.template row_dot<false, 1>(accq, L2C, [&](int n, int) { return th[d.qW3 + n]; }, L.part_q);
         u.template store_masks<1, false>(accq, L2C);
-        __syncthreads();
+        lds_barrier();
         float part_lp = 0.0f, part_qp = 0.0f;
         for (int b = tid; b < B; b += kThreads) {
             const float q = u.template part_sum<1>(L.part_q, b, 0) + th[d.qb3];
@@ -279,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             L.dml[b * NS + j] = dL_du;
             L.dml[b * NS + AD + j] = dL_dlogstd * HALF_RANGE * (1.0f - L.t[it] * L.t[it]);
         }
-        __syncthreads();
+        lds_barrier();
         // wave-local column reductions of the Q branch from the live (now relu'd) accumulators: d qW3, d qb2
         float g_qw3[NTW], g_qb2[NTW];
         {
@@ -342,16 +382,17 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         // this wave's first two weight-gradient items of pW2 (all it has at widths <= 128): W / m / v / W' in flight NOW,
         // under the backward GEMM, not under one k-loop (RLC_NO_EARLY_PREFETCH: the round-2 order, for A/B runs)
         typename U::WgPre2 pre;
-        const typename U::WgPre2* prep = nullptr;
-#ifndef RLC_NO_EARLY_PREFETCH
+#ifdef RLC_EARLY_PREFETCH
+        constexpr int NPRE = 2;
         u.wgrad_prefetch(pre, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, tt + d.pW2);
-        prep = &pre;
+#else
+        constexpr int NPRE = 0;
 #endif
         u.template bwd_gemm<NS, 0>(acc, th + d.pW2, L2A, L1A, L.dml, L.wvec);
-        __syncthreads();
+        lds_barrier();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_p, d.pW1, d.pb1, tapg, tt, tau, L.xc);
-        u.template wgrad_adam<NS, 0, 0>(L.dml, nullptr, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, alpha_p,
-                                        tapg ? tapg + d.pW2 : nullptr, tt + d.pW2, tau, L.wvec, prep);
+        u.template wgrad_adam_pre<NS, 0, 0, false, false, NPRE>(L.dml, nullptr, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, alpha_p,
+                                        tapg ? tapg + d.pW2 : nullptr, tt + d.pW2, tau, L.wvec, pre);
         {
             const int NT = (L2A + 15) >> 4;
 #pragma unroll
@@ -379,20 +420,24 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 if (u.lane == 0) U::adam_scalar(th, mm, vv, tt, tapg, j < AD ? d.pbm + j : d.pbs + (j - AD), gr, alpha_p, tau);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ================= 6: Q step =================
         u.H1 = L1C;
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1q, (const lds_f32*)(L.w1q + S * L1C), L.x);
+#else
         u.trunk(th + d.qW1, th + d.qb1, L.x);
+#endif
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < L2C ? th[d.qW3 + n] : 0.0f;
-        __syncthreads();
-#ifndef RLC_NO_EARLY_PREFETCH
+        lds_barrier();
+#ifdef RLC_EARLY_PREFETCH
         u.wgrad_prefetch(pre, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, tt + d.qW2);
 #endif
         u.template bwd_gemm<1, 1>(acc, th + d.qW2, L2C, L1C, L.dout, L.wvec);
-        __syncthreads();
+        lds_barrier();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_v, d.qW1, d.qb1, tapg, tt, tau, L.x);
-        u.template wgrad_adam<1, AD, 1>(L.dout, L.a, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, alpha_v,
-                                        tapg ? tapg + d.qW2 : nullptr, tt + d.qW2, tau, L.wvec, prep);
+        u.template wgrad_adam_pre<1, AD, 1, false, false, NPRE>(L.dout, L.a, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, alpha_v,
+                                        tapg ? tapg + d.qW2 : nullptr, tt + d.qW2, tau, L.wvec, pre);
         {
             const int NT = (L2C + 15) >> 4;
 #pragma unroll
@@ -411,16 +456,20 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 if (u.lane == 0) U::adam_scalar(th, mm, vv, tt, tapg, d.qb3, gr, alpha_v, tau);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ================= 7: V forward + step =================
+#ifdef RLC_W1_STAGE
+        u.trunk((const lds_f32*)L.w1v, (const lds_f32*)(L.w1v + S * L1C), L.xc);
+#else
         u.trunk(th + d.vW1, th + d.vb1, L.xc);
+#endif
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < L2C ? th[d.vW3 + n] : 0.0f;
-        __syncthreads();
+        lds_barrier();
         u.fwd_gemm(acc, th + d.vW2, L2C, L1C);
         u.template bias_relu<0>(acc, th + d.vb2, L2C);
         u.template row_dot<false, 1>(acc, L2C, [&](int n, int) { return L.wvec[n]; }, L.part_q);
         u.template store_masks<0, true>(acc, L2C);
-        __syncthreads();
+        lds_barrier();
         {   // v, its seed (quirk Q9), taps + losses (the reference fetches pi_loss, q_loss, v_loss: sac_network.py:135-136)
             float ql = 0.0f, vl = 0.0f;
             for (int b = tid; b < B; b += kThreads) {
@@ -443,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 dv.tap_loss[agent * 4 + 2] = 0.5f * vl * invB * invB;
             }
         }
-        __syncthreads();
+        lds_barrier();
         float g_vw3[NTW], g_vb2[NTW];
         {
             const int NT = (L2C + 15) >> 4;
@@ -467,14 +516,14 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 g_vb2[i] = col4_sum(s2);
             }
         }
-#ifndef RLC_NO_EARLY_PREFETCH
+#ifdef RLC_EARLY_PREFETCH
         u.wgrad_prefetch(pre, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, tt + d.vW2);
 #endif
         u.template bwd_gemm<1, 0>(acc, th + d.vW2, L2C, L1C, L.dvs, L.wvec);
-        __syncthreads();
+        lds_barrier();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_v, d.vW1, d.vb1, tapg, tt, tau, L.xc);
-        u.template wgrad_adam<1, 0, 0>(L.dvs, nullptr, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, alpha_v,
-                                       tapg ? tapg + d.vW2 : nullptr, tt + d.vW2, tau, L.wvec, prep);
+        u.template wgrad_adam_pre<1, 0, 0, false, false, NPRE>(L.dvs, nullptr, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, alpha_v,
+                                       tapg ? tapg + d.vW2 : nullptr, tt + d.vW2, tau, L.wvec, pre);
         {
             const int NT = (L2C + 15) >> 4;
 #pragma unroll

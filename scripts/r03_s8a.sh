@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/r03_s8
+rm -rf $OUT && mkdir -p $OUT
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $OUT/gpu_tests.log 2>&1; echo "gpu tests rc=$?" | tee -a $OUT/gpu_tests.log
+tail -4 $OUT/gpu_tests.log
+grep -q "rc=0" $OUT/gpu_tests.log || exit 1
+timeout -k 10 300 python scripts/bench_kl.py --tag r03 --cpu_updates 50 > $OUT/kl_bench.log 2>&1; tail -4 $OUT/kl_bench.log
