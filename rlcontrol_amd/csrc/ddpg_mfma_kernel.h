@@ -74,7 +74,9 @@ __host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, lds_u8* b
     return off;
 }
 
-template <int MT, int AD>
+// FUSE: the actor's and the critic's second layers have one width: their hidden contractions over one trunk image run
+// as ONE k-loop (target pair, online pair)
+template <int MT, int AD, bool FUSE>
 __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev dv, int first_agent, int n_updates,
                                                                         int source, const long long* host_idx,
                                                                         int grad_taps, const RlcRollout* rollout,
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     u.L.hbuf = L.hbuf; u.L.mask = L.mask; u.L.xbuf = L.xbuf;
     const int tid = u.tid, S = d.S, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
     const int agent = first_agent + blockIdx.x;
+    constexpr bool fuse_fwd = FUSE;      // the launcher picks FUSE when HA == HC
 
     float* th = dv.theta + (size_t)agent * d.Ppad;
     float* tt = dv.theta_t + (size_t)agent * d.Ppad;
@@ -210,7 +213,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #endif
         lds_barrier();
         STAMP();
-        u.fwd_gemm(acc, tt + d.oWa2, HA, H1);
+        // target actor and target critic read the same trunk image and the critic needs the actor's output only in its
+        // epilogue (the action rows): one k-loop for both hidden contractions when the two layers have one width
+        // (mfma_blocks.h fwd_gemm2; +0.9 % at the BASELINE shape, profiles/r03_variant_timings_s9.txt)
+        f32x4 acc2[MT][NTW];
+        if constexpr (fuse_fwd) u.fwd_gemm2(acc, acc2, tt + d.oWa2, tt + d.oWc2, HA, H1);
+        else u.fwd_gemm(acc, tt + d.oWa2, HA, H1);
         u.template bias_relu<0>(acc, tt + d.oba2, HA);
         u.template row_dot<false, AD>(acc, HA, [&](int n, int j) { return tt[d.oWa3 + n * AD + j]; }, L.part);   // z' partials
         lds_barrier();
@@ -221,7 +229,14 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         }
         lds_barrier();
         STAMP();
-        u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
+        if constexpr (fuse_fwd) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++) acc[mt][i] = acc2[mt][i];
+        } else {
+            u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
+        }
         u.template bias_relu<AD>(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2, d.arow0);
         u.template row_dot<false, 1>(acc, HC, [&](int n, int) { return tt[d.oWc3 + n]; }, L.part);      // q' partials
         lds_barrier();
@@ -356,7 +371,9 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         }
         __syncthreads();
         STAMP();
-        u.fwd_gemm(acc, th + d.oWa2, HA, H1);
+        f32x4 acc7[MT][NTW];          // the critic's hidden contraction at the new trunk (its action rows enter in the epilogue)
+        if constexpr (fuse_fwd) u.fwd_gemm2(acc, acc7, th + d.oWa2, th + d.oWc2, HA, H1);
+        else u.fwd_gemm(acc, th + d.oWa2, HA, H1);
         u.template bias_relu<0>(acc, th + d.oba2, HA);
         u.template row_dot<false, AD>(acc, HA, [&](int n, int j) { return th[d.oWa3 + n * AD + j]; }, L.part);   // z partials
         u.template store_masks<-2, true>(acc, HA);
@@ -380,7 +397,14 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             for (int i = 0; i < NTW; i++) h2acc[mt][i] = acc[mt][i];
 
         // ================= step 5: dQ/da at the scaled action, updated critic (DDPG.py:91) =================
-        u.fwd_gemm(acc, th + d.oWc2, HC, H1);
+        if constexpr (fuse_fwd) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++) acc[mt][i] = acc7[mt][i];
+        } else {
+            u.fwd_gemm(acc, th + d.oWc2, HC, H1);
+        }
         u.template bias_relu<AD>(acc, th + d.obc2, HC, L.aout, th + d.oWc2, d.arow0);
         // dqda[b][j] = sum_n step(g2[b][n]) * Wc3[n] * Wc2[H1+j][n]
         u.template row_dot<true, AD>(acc, HC, [&](int n, int j) { return th[d.oWc2 + rlc_blk_index(d.arow0 + j, n, HC)] * th[d.oWc3 + n]; },
@@ -492,12 +516,12 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #endif
 }
 
-template <int MT, int AD>
-int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
-             int grad_taps, hipStream_t st, const RlcRollout* rollout, int q8_first) {
+template <int MT, int AD, bool FUSE>
+int launch_tf(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
+              int grad_taps, hipStream_t st, const RlcRollout* rollout, int q8_first) {
     const size_t lds = smem_carve(dv.d, MT, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "MFMA DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = rlc_ddpg_update_mfma_kernel<MT, AD>;
+    auto kern = rlc_ddpg_update_mfma_kernel<MT, AD, FUSE>;
     static bool attr_set = false;
     if (!attr_set) {
         RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -507,6 +531,16 @@ int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int
                        grad_taps, rollout, q8_first);
     RLC_HIP(hipGetLastError());
     return 0;
+}
+
+template <int MT, int AD>
+int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
+             int grad_taps, hipStream_t st, const RlcRollout* rollout, int q8_first) {
+#ifndef RLC_DDPG_SEPARATE_FWD
+    if (dv.d.HA == dv.d.HC)
+        return launch_tf<MT, AD, true>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);
+#endif
+    return launch_tf<MT, AD, false>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);
 }
 
 }  // namespace

@@ -173,6 +173,20 @@ struct BlkLds {
 };
 
 struct NoExtra {};
+// A further contribution to dL/dh1[b][k] from heads that hang off the first layer (NAF's L heads): head gradients
+// dhd [MB][4] (LDS, zero beyond the heads in use) times head weights wh [4][256] (LDS).  The column's four weights are
+// read once per column (HeadExtra::column), the row's gradients once per element (HeadExtra::at): one LDS read per
+// element instead of four, and no branch around them.
+struct HeadExtra {
+    const RLC_LDS float* dhd;
+    const RLC_LDS float* wh;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ f4 column(int k) const { return f4{wh[k], wh[256 + k], wh[512 + k], wh[768 + k]}; }
+    __device__ __forceinline__ float at(const f4& w, int b) const {
+        const f4 dh = *reinterpret_cast<const RLC_LDS f4*>(&dhd[b * 4]);
+        return dh[0] * w[0] + dh[1] * w[1] + dh[2] * w[2] + dh[3] * w[3];
+    }
+};
 
 // Adam on the small tensors (first layer, a concat layer's extra rows): the hardware-sqrt/rcp form like the big
 // matrices' epilogue unless the build asks for the IEEE-exact expansions
@@ -501,6 +515,179 @@ struct Blk {
 #ifdef RLC_STAMPS
         if (lane == 0 && stamp_buf) stamp_buf[48 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
 #endif
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // TWO forward GEMMs over the same activation image in one k-loop: accA = hbuf . WA, accB = hbuf . WB (same N and K;
+    // e.g. NAF's mu and V branches, DDPG's actor and critic second layers).  Every A fragment read from LDS feeds twice
+    // the MFMAs, one loop prologue / drain and one barrier fall away, and neither accumulator set has to be parked in
+    // registers across the other GEMM's loop (where the compiler spilled it: NAF 224 VGPRs = 0.6 MB of scratch traffic
+    // per update).  Same structure and pinning as fwd_loop; summation order per output element unchanged.
+    // ---------------------------------------------------------------------------------------
+    template <int NOWN, bool XTRA>
+    __device__ __forceinline__ void fwd_loop2(f32x4 (&accA)[MT][NTW], f32x4 (&accB)[MT][NTW], const float* WA, const float* WB,
+                                              int NT, int KB, bool tail8, f32x4 (&accxA)[MXS], f32x4 (&accxB)[MXS], int xt,
+                                              int xm0) {
+        const int lofs = ((((c >> 2) << 4) + 4 * g) << 2) + (c & 3);
+        const size_t t0 = ((size_t)tile0() << 8) + lofs;
+        const float* wpA = WA + t0;
+        const float* wpB = WB + t0;
+        const int tst = tstep() << 8;
+        const size_t wstep = (size_t)NT << 8;
+        const lds_f32* ap = L.hbuf + c * LDH + 4 * g;
+        f32x4 a0[MT], a1[MT];
+        float b0[2][NOWN][4], b1[2][NOWN][4];
+        const size_t tx = ((size_t)xt << 8) + lofs;
+        const float* wpxA = WA + tx;
+        const float* wpxB = WB + tx;
+        const lds_f32* apx = ap + 16 * xm0 * LDH;
+        f32x4 ax0[MXS], ax1[MXS];
+        float bx0[2][4], bx1[2][4];
+        auto loadX = [&](f32x4 (&da)[MXS], float (&db)[2][4], int ch) {
+            if (XTRA) {
+#pragma unroll
+                for (int m = 0; m < MXS; m++)
+                    da[m] = *reinterpret_cast<const lds_f32x4*>(apx + 16 * (xm0 + m < MT ? m : 0) * LDH + 16 * ch);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++) {
+                    db[0][s2] = wpxA[(size_t)ch * wstep + 4 * s2];
+                    db[1][s2] = wpxB[(size_t)ch * wstep + 4 * s2];
+                }
+            }
+        };
+        auto macX = [&](const f32x4 (&da)[MXS], const float (&db)[2][4]) {
+            if (XTRA) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++)
+#pragma unroll
+                    for (int m = 0; m < MXS; m++) {
+                        accxA[m] = mfma16(da[m][s2], db[0][s2], accxA[m]);
+                        accxB[m] = mfma16(da[m][s2], db[1][s2], accxB[m]);
+                    }
+            }
+        };
+        auto loadA = [&](f32x4 (&dst)[MT], int ch) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const lds_f32x4*>(ap + 16 * mt * LDH + 16 * ch);
+        };
+        auto loadB = [&](float (&dst)[2][NOWN][4], int ch) {
+#pragma unroll
+            for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    dst[0][i][s] = wpA[(size_t)ch * wstep + i * tst + 4 * s];
+                    dst[1][i][s] = wpB[(size_t)ch * wstep + i * tst + 4 * s];
+                }
+        };
+        auto mac = [&](const f32x4 (&a)[MT], const float (&b)[2][NOWN][4]) {
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        accA[mt][i] = mfma16(a[mt][s], b[0][i][s], accA[mt][i]);
+                        accB[mt][i] = mfma16(a[mt][s], b[1][i][s], accB[mt][i]);
+                    }
+        };
+        loadB(b0, 0);
+        loadA(a0, 0);
+        loadX(ax0, bx0, 0);
+        int ch = 0;
+        auto pin = [&]() {
+            __builtin_amdgcn_sched_group_barrier(0x020, 8 * NOWN + (XTRA ? 8 : 0), 0);      // VMEM read
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NOWN, 0);      // MFMA
+            }
+            if (XTRA) {
+                __builtin_amdgcn_sched_group_barrier(0x100, MXS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * MXS, 0);
+            }
+        };
+        for (; ch + 2 <= KB; ch += 2) {
+            loadB(b1, ch + 1);
+            loadA(a1, ch + 1);
+            loadX(ax1, bx1, ch + 1);
+            mac(a0, b0);
+            macX(ax0, bx0);
+            pin();
+            const int nx = ch + 2 < KB ? ch + 2 : KB - 1;
+            loadB(b0, nx);
+            loadA(a0, nx);
+            loadX(ax0, bx0, nx);
+            mac(a1, b1);
+            macX(ax1, bx1);
+            pin();
+        }
+        if (ch < KB) { mac(a0, b0); macX(ax0, bx0); }
+        if (tail8) {
+            const lds_f32* at = L.hbuf + c * LDH + 16 * KB + 2 * g;
+            const int tofs = ((((c >> 2) << 4) + 2 * g) << 2) + (c & 3);
+            const size_t tb = ((size_t)tile0() << 8) + (size_t)KB * wstep + tofs;
+            float bt[2][NOWN][2];
+#pragma unroll
+            for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    bt[0][i][s2] = WA[tb + i * tst + 4 * s2];
+                    bt[1][i][s2] = WB[tb + i * tst + 4 * s2];
+                }
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 av[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) av[mt] = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * mt * LDH);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int i = 0; i < NOWN; i++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++) {
+                        accA[mt][i] = mfma16(av[mt][s2], bt[0][i][s2], accA[mt][i]);
+                        accB[mt][i] = mfma16(av[mt][s2], bt[1][i][s2], accB[mt][i]);
+                    }
+            if (XTRA) {
+                const size_t txb = ((size_t)xt << 8) + (size_t)KB * wstep + tofs;
+#pragma unroll
+                for (int m = 0; m < MXS; m++) {
+                    const f32x2 avx = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * (xm0 + m < MT ? xm0 + m : xm0) * LDH);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; s2++) {
+                        accxA[m] = mfma16(avx[s2], WA[txb + 4 * s2], accxA[m]);
+                        accxB[m] = mfma16(avx[s2], WB[txb + 4 * s2], accxB[m]);
+                    }
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void fwd_gemm2(f32x4 (&accA)[MT][NTW], f32x4 (&accB)[MT][NTW], const float* WA, const float* WB,
+                                              int N, int K) {
+        const int NT = (N + 15) >> 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int i = 0; i < NTW; i++) { accA[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; accB[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if constexpr (ablate(6)) return;
+        const int nown = nown_of(NT);
+        const bool tail8 = (K & 15) == 8 && K > 16;
+        const int KB = tail8 ? K >> 4 : (K + 15) >> 4;
+        f32x4 accxA[MXS], accxB[MXS];
+        if constexpr (NTW >= 2) {
+            if (split_mode(NT)) {
+#pragma unroll
+                for (int m = 0; m < MXS; m++) { accxA[m] = f32x4{0.f, 0.f, 0.f, 0.f}; accxB[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                if (wave >= 4) fwd_loop2<1, true>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, NT - 1, share_lo(wave - 4));
+                else fwd_loop2<2, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+                collect_split<false>(accA, accxA);
+                __syncthreads();                 // wave 4 has taken the first set out of the hand-off buffer
+                collect_split<false>(accB, accxB);
+            } else if (nown >= 2) fwd_loop2<2, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+            else if (nown == 1) fwd_loop2<1, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+        } else {
+            if (nown >= 1) fwd_loop2<1, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+        }
     }
 
     // acc = relu(acc + bias[n] + sum_j E[b][j] * Wx[xrow0+j][n])        (E = extra input columns of a concat layer)
@@ -962,8 +1149,14 @@ struct Blk {
             float gw[SP];
 #pragma unroll
             for (int s = 0; s < SP; s++) gw[s] = 0.0f;
+            HeadExtra::f4 hcolw = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (std::is_same<EXTRA, HeadExtra>::value) hcolw = extra.column(k < H1 ? k : 0);
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++)
+            for (int mt = 0; mt < MT; mt++) {
+                // with a head term per element (NAF) the scheduler otherwise hoists every LDS read of the unrolled loop to
+                // the front and spills the accumulators it still needs (550 scratch reloads in this function alone)
+                if constexpr (!std::is_same<EXTRA, NoExtra>::value && !std::is_same<EXTRA, HeadExtra>::value)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int b = 16 * mt + 4 * g + r;
@@ -971,6 +1164,9 @@ struct Blk {
                     float d;
                     if constexpr (std::is_same<EXTRA, NoExtra>::value) {
                         d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] : 0.0f;
+                    } else if constexpr (std::is_same<EXTRA, HeadExtra>::value) {
+                        const float e = extra.at(hcolw, b);
+                        d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] + e : 0.0f;
                     } else {
                         d = (k < H1 && hv > 0.0f) ? acc[mt][i][r] + extra(b, k < H1 ? k : 0) : 0.0f;
                     }
@@ -984,6 +1180,7 @@ struct Blk {
                         for (int s = 0; s < 4; s++) gw[(SP > 4 ? 4 : 0) + s] += x1[s] * d;
                     }
                 }
+            }
             gb = col4_sum(gb);
 #pragma unroll
             for (int s = 0; s < SP; s++) gw[s] = col4_sum(gw[s]);

@@ -222,12 +222,20 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             }
         }
         f32x4 acca[MT][NTW];
+#ifndef RLC_NAF_SEPARATE_FWD
+        // the mu and V branches read the same trunk image: one k-loop for both (mfma_blocks.h fwd_gemm2)
+        u.fwd_gemm2(acca, acc, th + d.Wa2, th + d.Wv2, L2, L1);
+        u.template bias_relu<0>(acca, th + d.ba2, L2);
+        u.template row_dot<false, AD>(acca, L2, [&](int n, int j) { return L.wvec[j * 256 + n]; }, L.part_a);
+        u.template store_masks<0, true>(acca, L2);
+#else
         u.fwd_gemm(acca, th + d.Wa2, L2, L1);
         u.template bias_relu<0>(acca, th + d.ba2, L2);
         u.template row_dot<false, AD>(acca, L2, [&](int n, int j) { return L.wvec[j * 256 + n]; }, L.part_a);
         u.template store_masks<0, true>(acca, L2);
         if (u.split_mode((L2 + 15) >> 4)) lds_barrier();      // the split tile's hand-off buffer is reused
         u.fwd_gemm(acc, th + d.Wv2, L2, L1);
+#endif
         u.template bias_relu<0>(acc, th + d.bv2, L2);
         u.template row_dot<false, 1>(acc, L2, [&](int n, int) { return wv3[n]; }, L.part_v);
         u.template store_masks<1, false>(acc, L2);
@@ -335,13 +343,8 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
 #else
         constexpr int NPRE = 0;
 #endif
-        u.trunk_grad_adam(acc, th, mm, vv, alpha, d.W1, d.b1, tapg, tt, tau, L.x, [&](int b, int k) {
-            const f32x4 dh = *reinterpret_cast<const lds_f32x4*>(&L.dhd[b * NHP]);
-            float e = 0.0f;
-#pragma unroll
-            for (int j = 0; j < NH; j++) e += dh[j] * L.wh[j * 256 + k];
-            return e;
-        });
+        // heads off the trunk: dL/dh1[b][k] += sum_j dhd[b][j] * wh[j][k]  (dhd / wh rows beyond the NH heads in use are zero)
+        u.trunk_grad_adam(acc, th, mm, vv, alpha, d.W1, d.b1, tapg, tt, tau, L.x, HeadExtra{L.dhd, L.wh});
         // head weights: g[k][j] = sum_b h1[b][k] dhd[b][j] (thread k), head biases (wave j)
         for (int k = tid; k < L1; k += kThreads) {
             float gs[NH];
