@@ -321,6 +321,8 @@ typedef struct rlc_naf_config {
     const float* action_max;     /* [action_dim] scale of tanh (naf_network.py:89) */
     const float* learning_rate;  /* [n_agents] */
     const uint64_t* seed;        /* [n_agents] Philox keys of the device sampler */
+    const float* action_min;     /* [action_dim] lower clip of the exploration draw in the on-device loop
+                                  * (naf_network.py:176 clips to [action_min, action_max]); NULL: -action_max */
 } rlc_naf_config;
 
 int rlc_naf_create(const rlc_naf_config* cfg, rlc_naf** out);

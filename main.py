@@ -148,15 +148,12 @@ def _make_population(agent_name, members, arg_params):
         from rlcontrol_amd.hip_naf import NAFPopulation, init_params
         if c0.exploration_policy != 'none':
             raise RuntimeError("the device loop implements NAF's own covariance exploration (exploration_policy 'none')")
-        if not np.allclose(np.asarray(c0.action_min, np.float64), -np.asarray(c0.action_max, np.float64)):
-            # the reference clips the draw to [action_min, action_max] (naf_network.py:176); the device draw clips to
-            # +-action_max, which is the same thing only for a symmetric box
-            raise ValueError("the NAF device loop needs a symmetric action box (action_min == -action_max)")
         pop = NAFPopulation(
             n_agents=len(members), state_dim=c0.state_dim, action_dim=c0.action_dim, l1_dim=c0.l1_dim, l2_dim=c0.l2_dim,
             batch_size=c0.batch_size, buffer_size=int(c0.buffer_size), tau=c0.tau, state_min=c0.state_min,
             state_max=c0.state_max, action_max=c0.action_max, learning_rate=[m[3].learning_rate for m in members],
-            seeds=seeds, clip_state=(c0.norm_type != 'none'), device=device, norm_type=c0.norm_type)
+            seeds=seeds, clip_state=(c0.norm_type != 'none'), device=device, norm_type=c0.norm_type,
+            action_min=c0.action_min)       # the draw is clipped to [action_min, action_max] (naf_network.py:176)
         for i, m in enumerate(members):
             pop.set_params(i, init_params(c0.state_dim, c0.action_dim, c0.l1_dim, c0.l2_dim, m[3].random_seed,
                                           c0.norm_type), init_target=True)

@@ -251,11 +251,12 @@ class NafRolloutOracle(RolloutOracle):
 
     def __init__(self, dims, theta, lr, tau, state_min, state_max, action_max, noise_scale, seed, batch_size,
                  buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes,
-                 norm_type="input_norm"):
+                 norm_type="input_norm", action_min=None):
         self._naf = (lr, norm_type)
         self.noise_scale = np.float32(noise_scale)
         amax = np.asarray(action_max, np.float32).reshape(-1)
-        RolloutOracle.__init__(self, dims, theta, 0.0, 0.0, tau, state_min, state_max, -amax, amax, seed, batch_size,
+        amin = -amax if action_min is None else np.asarray(action_min, np.float32).reshape(-1)
+        RolloutOracle.__init__(self, dims, theta, 0.0, 0.0, tau, state_min, state_max, amin, amax, seed, batch_size,
                                buffer_size, gamma, warmup_steps, episode_limit, total_steps, eval_interval, eval_episodes)
 
     def _make_net(self, dims, theta, actor_lr, critic_lr, tau, state_min, state_max, action_max, clip_state):

@@ -100,7 +100,7 @@ class rlc_naf_config(ctypes.Structure):
         ("tau", ctypes.c_float), ("norm_type", ctypes.c_int32),
         ("state_min", ctypes.POINTER(ctypes.c_float)), ("state_max", ctypes.POINTER(ctypes.c_float)),
         ("action_max", ctypes.POINTER(ctypes.c_float)), ("learning_rate", ctypes.POINTER(ctypes.c_float)),
-        ("seed", ctypes.POINTER(ctypes.c_uint64)),
+        ("seed", ctypes.POINTER(ctypes.c_uint64)), ("action_min", ctypes.POINTER(ctypes.c_float)),
     ]
 
 

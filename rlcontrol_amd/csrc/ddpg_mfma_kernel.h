@@ -187,14 +187,14 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
             } else {
                 const size_t slot = (size_t)agent * dv.rep.cap + ring_slot(ring, dv.rep.cap, L.idx[b]);
                 ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot * AD; ps2 = dv.rep.rs2 + slot * S;
-                L.r[b] = dv.rep.rr[slot]; L.g[b] = dv.rep.rg[slot];
+                L.r[b] = ld_gather(&dv.rep.rr[slot]); L.g[b] = ld_gather(&dv.rep.rg[slot]);
             }
             for (int i = 0; i < S; i++) {
-                L.x[b * SMAX + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
-                L.x2[b * SMAX + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x[b * SMAX + i] = clip_state_val(ld_gather(&ps[i]), dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x2[b * SMAX + i] = clip_state_val(ld_gather(&ps2[i]), dv.clip_state, dv.smin[i], dv.smax[i]);
             }
 #pragma unroll
-            for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
+            for (int j = 0; j < AD; j++) L.a[b * AD + j] = ld_gather(&pa[j]);
         }
         u.sub_stamp(27);
         }
@@ -217,8 +217,8 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         // epilogue (the action rows): one k-loop for both hidden contractions when the two layers have one width
         // (mfma_blocks.h fwd_gemm2; +0.9 % at the BASELINE shape, profiles/r03_variant_timings_s9.txt)
         f32x4 acc2[MT][NTW];
-        if constexpr (fuse_fwd) u.fwd_gemm2(acc, acc2, tt + d.oWa2, tt + d.oWc2, HA, H1);
-        else u.fwd_gemm(acc, tt + d.oWa2, HA, H1);
+        if constexpr (fuse_fwd) u.template fwd_gemm2<true>(acc, acc2, tt + d.oWa2, tt + d.oWc2, HA, H1);
+        else u.template fwd_gemm<true>(acc, tt + d.oWa2, HA, H1);
         u.template bias_relu<0>(acc, tt + d.oba2, HA);
         u.template row_dot<false, AD>(acc, HA, [&](int n, int j) { return tt[d.oWa3 + n * AD + j]; }, L.part);   // z' partials
         lds_barrier();
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #pragma unroll
                 for (int i = 0; i < NTW; i++) acc[mt][i] = acc2[mt][i];
         } else {
-            u.fwd_gemm(acc, tt + d.oWc2, HC, H1);
+            u.template fwd_gemm<true>(acc, tt + d.oWc2, HC, H1);
         }
         u.template bias_relu<AD>(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2, d.arow0);
         u.template row_dot<false, 1>(acc, HC, [&](int n, int) { return tt[d.oWc3 + n]; }, L.part);      // q' partials

@@ -120,6 +120,23 @@ __device__ __forceinline__ void st_stream(float* p, f32x4 v) {
 #endif
 }
 
+// a replay field of the minibatch gather: a random 64-byte sector per field and sample, never re-read
+template <class T>
+__device__ __forceinline__ T ld_gather(const T* p) {
+#ifdef RLC_NT_GATHER
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+// a weight dword of a forward k-loop; STREAM: the matrix is read once per update by this GEMM (a target network's): nt
+template <bool STREAM>
+__device__ __forceinline__ float ld_w(const float* p) {
+#ifdef RLC_NT_TARGET_GEMM
+    if constexpr (STREAM) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
 __device__ __forceinline__ f32x4 ld_target(const float* p) {
 #ifdef RLC_NT_TARGET
     return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
@@ -343,7 +360,7 @@ struct Blk {
     // MT ds_read_b128 + 4*NOWN global_load_dword + 4*MT*NOWN MFMAs and little else.
     // ---------------------------------------------------------------------------------------
     // XTRA: besides its NOWN full tiles the wave computes batch tiles [xm0, xm0 + xnm) of the split tile xt into accx
-    template <int NOWN, bool XTRA>
+    template <int NOWN, bool XTRA, bool STREAM = false>
     __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB, bool tail8,
                                              f32x4 (&accx)[MXS], int xt, int xm0) {
         const int lofs = ((((c >> 2) << 4) + 4 * g) << 2) + (c & 3);
@@ -364,7 +381,7 @@ struct Blk {
                 for (int m = 0; m < MXS; m++)      // a share shorter than MXS repeats its first tile (result unused)
                     da[m] = *reinterpret_cast<const lds_f32x4*>(apx + 16 * (xm0 + m < MT ? m : 0) * LDH + 16 * ch);
 #pragma unroll
-                for (int s2 = 0; s2 < 4; s2++) db[s2] = wpx[(size_t)ch * wstep + 4 * s2];
+                for (int s2 = 0; s2 < 4; s2++) db[s2] = ld_w<STREAM>(&wpx[(size_t)ch * wstep + 4 * s2]);
             }
         };
         auto macX = [&](const f32x4 (&da)[MXS], const float (&db)[4]) {
@@ -383,7 +400,7 @@ struct Blk {
 #pragma unroll
             for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                for (int s = 0; s < 4; s++) dst[i][s] = wp[(size_t)ch * wstep + i * tst + 4 * s];
+                for (int s = 0; s < 4; s++) dst[i][s] = ld_w<STREAM>(&wp[(size_t)ch * wstep + i * tst + 4 * s]);
         };
         auto mac = [&](const f32x4 (&a)[MT], const float (&b)[NOWN][4]) {
 #pragma unroll
@@ -486,6 +503,7 @@ struct Blk {
         }
     }
 
+    template <bool STREAM = false>
     __device__ __forceinline__ void fwd_gemm(f32x4 (&acc)[MT][NTW], const float* W, int N, int K) {
         const int NT = (N + 15) >> 4;
 #pragma unroll
@@ -504,13 +522,13 @@ struct Blk {
             if (split_mode(NT)) {                  // workgroup-uniform
 #pragma unroll
                 for (int m = 0; m < MXS; m++) accx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (wave >= 4) fwd_loop<1, true>(acc, W, NT, KB, tail8, accx, NT - 1, share_lo(wave - 4));
-                else fwd_loop<2, false>(acc, W, NT, KB, tail8, accx, 0, 0);
+                if (wave >= 4) fwd_loop<1, true, STREAM>(acc, W, NT, KB, tail8, accx, NT - 1, share_lo(wave - 4));
+                else fwd_loop<2, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
                 collect_split<false>(acc, accx);
-            } else if (nown >= 2) fwd_loop<2, false>(acc, W, NT, KB, tail8, accx, 0, 0);
-            else if (nown == 1) fwd_loop<1, false>(acc, W, NT, KB, tail8, accx, 0, 0);
+            } else if (nown >= 2) fwd_loop<2, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
+            else if (nown == 1) fwd_loop<1, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
         } else {
-            if (nown >= 1) fwd_loop<1, false>(acc, W, NT, KB, tail8, accx, 0, 0);
+            if (nown >= 1) fwd_loop<1, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
         }
 #ifdef RLC_STAMPS
         if (lane == 0 && stamp_buf) stamp_buf[48 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
@@ -524,7 +542,7 @@ struct Blk {
     // registers across the other GEMM's loop (where the compiler spilled it: NAF 224 VGPRs = 0.6 MB of scratch traffic
     // per update).  Same structure and pinning as fwd_loop; summation order per output element unchanged.
     // ---------------------------------------------------------------------------------------
-    template <int NOWN, bool XTRA>
+    template <int NOWN, bool XTRA, bool STREAM = false>
     __device__ __forceinline__ void fwd_loop2(f32x4 (&accA)[MT][NTW], f32x4 (&accB)[MT][NTW], const float* WA, const float* WB,
                                               int NT, int KB, bool tail8, f32x4 (&accxA)[MXS], f32x4 (&accxB)[MXS], int xt,
                                               int xm0) {
@@ -550,8 +568,8 @@ struct Blk {
                     da[m] = *reinterpret_cast<const lds_f32x4*>(apx + 16 * (xm0 + m < MT ? m : 0) * LDH + 16 * ch);
 #pragma unroll
                 for (int s2 = 0; s2 < 4; s2++) {
-                    db[0][s2] = wpxA[(size_t)ch * wstep + 4 * s2];
-                    db[1][s2] = wpxB[(size_t)ch * wstep + 4 * s2];
+                    db[0][s2] = ld_w<STREAM>(&wpxA[(size_t)ch * wstep + 4 * s2]);
+                    db[1][s2] = ld_w<STREAM>(&wpxB[(size_t)ch * wstep + 4 * s2]);
                 }
             }
         };
@@ -575,8 +593,8 @@ struct Blk {
             for (int i = 0; i < NOWN; i++)
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
-                    dst[0][i][s] = wpA[(size_t)ch * wstep + i * tst + 4 * s];
-                    dst[1][i][s] = wpB[(size_t)ch * wstep + i * tst + 4 * s];
+                    dst[0][i][s] = ld_w<STREAM>(&wpA[(size_t)ch * wstep + i * tst + 4 * s]);
+                    dst[1][i][s] = ld_w<STREAM>(&wpB[(size_t)ch * wstep + i * tst + 4 * s]);
                 }
         };
         auto mac = [&](const f32x4 (&a)[MT], const float (&b)[2][NOWN][4]) {
@@ -662,6 +680,7 @@ struct Blk {
         }
     }
 
+    template <bool STREAM = false>
     __device__ __forceinline__ void fwd_gemm2(f32x4 (&accA)[MT][NTW], f32x4 (&accB)[MT][NTW], const float* WA, const float* WB,
                                               int N, int K) {
         const int NT = (N + 15) >> 4;
@@ -678,15 +697,15 @@ struct Blk {
             if (split_mode(NT)) {
 #pragma unroll
                 for (int m = 0; m < MXS; m++) { accxA[m] = f32x4{0.f, 0.f, 0.f, 0.f}; accxB[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                if (wave >= 4) fwd_loop2<1, true>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, NT - 1, share_lo(wave - 4));
-                else fwd_loop2<2, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+                if (wave >= 4) fwd_loop2<1, true, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, NT - 1, share_lo(wave - 4));
+                else fwd_loop2<2, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
                 collect_split<false>(accA, accxA);
                 __syncthreads();                 // wave 4 has taken the first set out of the hand-off buffer
                 collect_split<false>(accB, accxB);
-            } else if (nown >= 2) fwd_loop2<2, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
-            else if (nown == 1) fwd_loop2<1, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+            } else if (nown >= 2) fwd_loop2<2, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+            else if (nown == 1) fwd_loop2<1, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
         } else {
-            if (nown >= 1) fwd_loop2<1, false>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+            if (nown >= 1) fwd_loop2<1, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
         }
     }
 
@@ -932,6 +951,12 @@ struct Blk {
                 dst[i] = *reinterpret_cast<const f32x4*>(wp + i * tst + ((size_t)ch << 8));
             if (XTRA) dx = *reinterpret_cast<const f32x4*>(wpx + ((size_t)ch << 8));
         };
+        // RLC_BWD_PREFETCH: the raw mask dwords of the NEXT chunk are read before the MFMAs of this one (MT registers)
+        unsigned mwn[MT];
+        auto load_masks = [&](int ch) {
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) mwn[mt] = *reinterpret_cast<const lds_u32*>(mp + 16 * mt * MSTRIDE + 16 * ch);
+        };
         auto mac = [&](const f32x4 (&bin)[NOWN], const f32x4& binx, int ch) {
             f32x4 wv[NS], b[NOWN], bx;
 #pragma unroll
@@ -942,7 +967,11 @@ struct Blk {
             f32x4 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
+#ifdef RLC_BWD_PREFETCH
+                unsigned mw = mwn[mt];
+#else
                 unsigned mw = *reinterpret_cast<const lds_u32*>(mp + 16 * mt * MSTRIDE + 16 * ch);
+#endif
                 if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x01010101u;
                 float mf[4];
                 mask4(mw, mf, std::integral_constant<int, BIT>{});
@@ -959,6 +988,9 @@ struct Blk {
                     }
                 }
             }
+#ifdef RLC_BWD_PREFETCH
+            load_masks(ch + 1 < NTk ? ch + 1 : ch);       // consumed by the next call (clamped on the last chunk)
+#endif
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -987,6 +1019,9 @@ struct Blk {
             }
         };
         loadB(b0, bx0, 0);
+#ifdef RLC_BWD_PREFETCH
+        load_masks(0);
+#endif
         int ch = 0;
         // one scheduling region per pair of chunks (see fwd_loop): next chunk's weight tile first, then per M tile
         // its mask dword read ahead of the 4*NOWN MFMAs that consume the previous one

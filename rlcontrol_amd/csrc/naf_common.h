@@ -60,6 +60,7 @@ struct RlcNafDev {
     float* pw;                        // [n_agents][2] beta powers
     const float* lr;                  // [n_agents]
     const float *smin, *smax, *amax;
+    const float* amin;            // lower clip of the exploration draw (on-device loop)
     float *tap_q, *tap_y, *tap_V, *tap_g;
     float* scratch;
     long long scratch_stride;

@@ -157,21 +157,21 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             } else {
                 const size_t slot = (size_t)agent * dv.rep.cap + ring_slot(ring, dv.rep.cap, L.idx[b]);
                 ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot * AD; ps2 = dv.rep.rs2 + slot * S;
-                L.r[b] = dv.rep.rr[slot]; L.g[b] = dv.rep.rg[slot];
+                L.r[b] = ld_gather(&dv.rep.rr[slot]); L.g[b] = ld_gather(&dv.rep.rg[slot]);
             }
             for (int i = 0; i < S; i++) {
-                L.x[b * SMAX + i] = clip_state_val(ps[i], dv.clip_state, dv.smin[i], dv.smax[i]);
-                L.x2[b * SMAX + i] = clip_state_val(ps2[i], dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x[b * SMAX + i] = clip_state_val(ld_gather(&ps[i]), dv.clip_state, dv.smin[i], dv.smax[i]);
+                L.x2[b * SMAX + i] = clip_state_val(ld_gather(&ps2[i]), dv.clip_state, dv.smin[i], dv.smax[i]);
             }
 #pragma unroll
-            for (int j = 0; j < AD; j++) L.a[b * AD + j] = pa[j];
+            for (int j = 0; j < AD; j++) L.a[b * AD + j] = ld_gather(&pa[j]);
         }
         lds_barrier();
 
         // ================= 1: target V'(s') and the float64 TD glue (agents/NAF.py:70) =================
         u.trunk(tt + d.W1, tt + d.b1, L.x2);
         lds_barrier();
-        u.fwd_gemm(acc, tt + d.Wv2, L2, L1);
+        u.template fwd_gemm<true>(acc, tt + d.Wv2, L2, L1);
         u.template bias_relu<0>(acc, tt + d.bv2, L2);
         u.template row_dot<false, 1>(acc, L2, [&](int n, int) { return tt[d.Wv3 + n]; }, L.part_v);
         lds_barrier();

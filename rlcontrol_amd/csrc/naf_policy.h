@@ -75,9 +75,9 @@ __device__ inline float naf_l_entry(const RlcNafDims& d, const NafPolicyLds& L, 
     return L.npre[off + (i - c - 1)];
 }
 
-// thread 0: L.out <- clip(mu + sqrt(noise_scale) * L^-T z, -a_max, a_max), z from the agent's Philox stream
-__device__ inline void naf_explore(const RlcNafDims& d, const NafPolicyLds& L, const float* amax, float noise_scale,
-                                   unsigned long long seed, unsigned long long ctr) {
+// thread 0: L.out <- clip(mu + sqrt(noise_scale) * L^-T z, a_min, a_max) (naf_network.py:176), z from the agent's Philox stream
+__device__ inline void naf_explore(const RlcNafDims& d, const NafPolicyLds& L, const float* amin, const float* amax,
+                                   float noise_scale, unsigned long long seed, unsigned long long ctr) {
     const int A = d.A;
     float y[RLC_NAF_MAX_A];
     const float sc = sqrtf(noise_scale);
@@ -92,7 +92,7 @@ __device__ inline void naf_explore(const RlcNafDims& d, const NafPolicyLds& L, c
         for (int j = i + 1; j < A; j++) s -= naf_l_entry(d, L, j, i) * y[j];
         y[i] = s / naf_l_entry(d, L, i, i);
     }
-    for (int j = 0; j < A; j++) L.out[j] = fminf(fmaxf(L.out[j] + y[j], -amax[j]), amax[j]);
+    for (int j = 0; j < A; j++) L.out[j] = fminf(fmaxf(L.out[j] + y[j], amin[j]), amax[j]);
 }
 
 #endif  // __HIPCC__

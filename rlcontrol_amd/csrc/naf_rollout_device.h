@@ -33,7 +33,7 @@ __device__ __noinline__ int rlc_naf_train_step_device(const RlcNafRollout* ro, i
     for (int i = tid; i < S; i += nthr) L.x[i] = clip_state_val((float)obs[i], dv.clip_state, dv.smin[i], dv.smax[i]);
     naf_policy_forward(d, th, L, dv.amax);
     if (tid == 0) {
-        naf_explore(d, L, dv.amax, ro->noise_scale[agent], dv.rep.seed[agent], ro->noise_ctr[agent]);
+        naf_explore(d, L, dv.amin, dv.amax, ro->noise_scale[agent], dv.rep.seed[agent], ro->noise_ctr[agent]);
         ro->noise_ctr[agent] += 1;
         *learn_flag = rlc_env_advance_store(dv.rep, env, agent, L.out);
     }

@@ -1,3 +1,4 @@
+#include <vector>
 // rlc_api_naf.hip -- C ABI of the NAF population (declared in include/rlcontrol_hip.h).
 #include <string.h>
 
@@ -95,9 +96,10 @@ int rlc_naf_create(const rlc_naf_config* cfg, rlc_handle** out) {
     TRY(rlc_h_malloc(h, &dv.m, NA * PP));
     TRY(rlc_h_malloc(h, &dv.v, NA * PP));
     TRY(rlc_h_malloc(h, &dv.pw, NA * 2));
-    float *lr, *smin, *smax, *amax;
+    float *lr, *smin, *smax, *amax, *amin;
     TRY(rlc_h_malloc(h, &lr, NA)); TRY(rlc_h_malloc(h, &smin, S)); TRY(rlc_h_malloc(h, &smax, S)); TRY(rlc_h_malloc(h, &amax, A));
-    dv.lr = lr; dv.smin = smin; dv.smax = smax; dv.amax = amax;
+    TRY(rlc_h_malloc(h, &amin, A));
+    dv.lr = lr; dv.smin = smin; dv.smax = smax; dv.amax = amax; dv.amin = amin;
     TRY(rlc_h_malloc(h, &dv.tap_q, NA * RLC_MAX_BATCH));
     TRY(rlc_h_malloc(h, &dv.tap_y, NA * RLC_MAX_BATCH));
     TRY(rlc_h_malloc(h, &dv.tap_V, NA * RLC_MAX_BATCH));
@@ -112,6 +114,9 @@ int rlc_naf_create(const rlc_naf_config* cfg, rlc_handle** out) {
     if (e == hipSuccess) e = hipMemcpyAsync(smin, cfg->state_min, S * sizeof(float), hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess) e = hipMemcpyAsync(smax, cfg->state_max, S * sizeof(float), hipMemcpyHostToDevice, h->st);
     if (e == hipSuccess) e = hipMemcpyAsync(amax, cfg->action_max, A * sizeof(float), hipMemcpyHostToDevice, h->st);
+    std::vector<float> amin_host(A);
+    for (int j = 0; j < A; j++) amin_host[j] = cfg->action_min ? cfg->action_min[j] : -cfg->action_max[j];
+    if (e == hipSuccess) e = hipMemcpy(amin, amin_host.data(), A * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamSynchronize(h->st);
     if (e != hipSuccess) {
         rlc_set_error("rlc_naf_create: upload failed: %s", hipGetErrorString(e));

@@ -187,16 +187,16 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             } else {
                 const size_t slot = (size_t)agent * dv.rep.cap + ring_slot(ring, dv.rep.cap, L.idx[b]);
                 ps = dv.rep.rs + slot * S; pa = dv.rep.ra + slot * AD; ps2 = dv.rep.rs2 + slot * S;
-                L.r[b] = (float)dv.rep.rr[slot]; L.g[b] = (float)dv.rep.rg[slot];
+                L.r[b] = (float)ld_gather(&dv.rep.rr[slot]); L.g[b] = (float)ld_gather(&dv.rep.rg[slot]);
             }
             for (int i = 0; i < S; i++) {
-                L.x[b * SMAX + i] = ps[i];
-                L.xc[b * SMAX + i] = rlc_clip_scalar(ps[i], dv.clip_state, dv.smin0, dv.smax0);
-                L.x2c[b * SMAX + i] = rlc_clip_scalar(ps2[i], dv.clip_state, dv.smin0, dv.smax0);
+                L.x[b * SMAX + i] = ld_gather(&ps[i]);
+                L.xc[b * SMAX + i] = rlc_clip_scalar(ld_gather(&ps[i]), dv.clip_state, dv.smin0, dv.smax0);
+                L.x2c[b * SMAX + i] = rlc_clip_scalar(ld_gather(&ps2[i]), dv.clip_state, dv.smin0, dv.smax0);
             }
 #pragma unroll
             for (int j = 0; j < AD; j++) {
-                L.a[b * AD + j] = pa[j];
+                L.a[b * AD + j] = ld_gather(&pa[j]);
                 float e;
                 if (eps_in) {
                     e = eps_in[(((size_t)blockIdx.x * n_updates + upd) * B + b) * AD + j];
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         u.trunk(tt + d.vW1, tt + d.vb1, L.x2c);
 #endif
         lds_barrier();
-        u.fwd_gemm(acc, tt + d.vW2, L2C, L1C);
+        u.template fwd_gemm<true>(acc, tt + d.vW2, L2C, L1C);
         u.template bias_relu<0>(acc, tt + d.vb2, L2C);
         u.template row_dot<false, 1>(acc, L2C, [&](int n, int) { return tt[d.vW3 + n]; }, L.part_q);
         lds_barrier();

@@ -58,7 +58,8 @@ class NAFPopulation(Population):
     TAP = {"q": 0, "y": 1, "V": 2, "grads": 3}
 
     def __init__(self, n_agents, state_dim, action_dim, l1_dim, l2_dim, batch_size, buffer_size, tau, state_min,
-                 state_max, action_max, learning_rate, seeds, clip_state=True, device=0, norm_type="input_norm"):
+                 state_max, action_max, learning_rate, seeds, clip_state=True, device=0, norm_type="input_norm",
+                 action_min=None):
         self._init_base(n_agents, state_dim, action_dim, batch_size)
         self.dims = (self.S, self.A, int(l1_dim), int(l2_dim))
         self.norm_type = norm_type
@@ -73,6 +74,9 @@ class NAFPopulation(Population):
         cfg.batch_size, cfg.clip_state, cfg.buffer_size, cfg.tau = self.B, 1 if clip_state else 0, int(buffer_size), float(tau)
         cfg.norm_type = NORM_TYPES[norm_type]
         cfg.state_min, cfg.state_max, cfg.action_max = fptr(self._keep["smin"]), fptr(self._keep["smax"]), fptr(self._keep["amax"])
+        # lower clip of the exploration draw in the on-device loop (naf_network.py:176); default: a symmetric box
+        self._keep["amin"] = bc(-np.asarray(self._keep["amax"]) if action_min is None else action_min, self.A)
+        cfg.action_min = fptr(self._keep["amin"])
         cfg.learning_rate = fptr(self._keep["lr"])
         cfg.seed = self._keep["seed"].ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
         check(self._lib.rlc_naf_create(ctypes.byref(cfg), ctypes.byref(self._h)))

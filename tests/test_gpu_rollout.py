@@ -361,6 +361,34 @@ def test_naf_rollout_matches_cpu_restatement(hip_lib, noise):
     pop.close()
 
 
+def test_naf_rollout_clips_to_an_asymmetric_action_box(hip_lib):
+    """naf_network.py:176 clips the exploration draw to [action_min, action_max]; rlc_naf_config::action_min carries the
+    lower bound to the on-device loop (default -action_max).  A large noise scale so that both bounds bite."""
+    from oracle.naf import NafDims, init_params
+    from oracle.rollout import NafRolloutOracle
+    from rlcontrol_amd.device_experiment import DeviceExperiment
+    from rlcontrol_amd.hip_naf import NAFPopulation
+    dims, B, seed, lr, amin = (3, 1, 32, 32), 16, 77, 1e-3, [-0.6]
+    pop = NAFPopulation(1, *dims, B, 4096, 0.01, SMIN, SMAX, AMAX, [lr], seeds=[seed], action_min=amin)
+    d = NafDims(*dims)
+    theta = init_params(d, 41)
+    pop.set_params(0, theta, init_target=True)
+    env = {"environment": "Pendulum-v0", "TotalMilSteps": 0.00006, "EpisodeSteps": 25,
+           "EvalIntervalMilSteps": 0.00004, "EvalEpisodes": 1}
+    exp = DeviceExperiment(pop, env, gamma=0.99, warmup_steps=0, noise_scale=3.0)
+    exp.advance(1000)
+    orc = NafRolloutOracle(d, theta, lr, 0.01, SMIN, SMAX, AMAX, 3.0, seed, B, 4096, 0.99, 0, 25, 60, 40, 1,
+                           action_min=amin).run()
+    n = pop.replay_size(0)
+    assert n == len(orc.replay)
+    _, act, _, _, _ = pop.replay_gather(0, np.arange(n))
+    oa = np.array([t[1] for t in orc.replay])
+    assert act.min() == np.float32(-0.6) and act.max() == np.float32(2.0)        # both bounds reached, neither exceeded
+    assert np.allclose(act[:B + 1], oa[:B + 1], atol=1e-5)                         # before the first update: same draws
+    assert np.mean(np.isclose(act, oa, atol=5e-3)) > 0.9
+    pop.close()
+
+
 def test_naf_layer_norm_rollout_matches_cpu_restatement(hip_lib):
     """norm_type 'layer' in the on-device loop: the training step, the fused update and the evaluation kernel all go
     through the three layer norms (naf_policy.h, naf_generic.hip) -- against the torch restatement on the same streams"""
