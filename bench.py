@@ -21,6 +21,7 @@ The JSON line also carries
                 intensity > 19.7 ridge), achieved = 73.2 MFLOP x updates per launch / HIP-event launch time
   roofline_hbm  the same launch priced in algorithmic HBM bytes (2,634,064 B per update) vs 8 TB/s
   cpu_baseline  the reference-structured CPU port (oracle/) timed on this host, rank 0 at N=1 only
+  ddpg_separate (N=1 only) the `network: separate` variant of DDPG on the MFMA kernel
   sac, naf      (N=1 only) the same measurement for BASELINE configs[2] / [3]: SoftActorCritic (S=3 A=1 L=128) and
                 NAF (S=8 A=2 L=200) fused update kernels, 256 agents x 1e6-record replays, each with its own
                 flop_per_update and roofline fraction; the DDPG headline stays `value`
@@ -266,6 +267,17 @@ def side_record(algo, NA, U, steps, warmup, torch, device):
         host = synthetic_uniform_replay(REPLAY_N, SAC_SHAPE["S"], SAC_SHAPE["A"])
         flop, byts = SAC_FLOP_PER_UPDATE, SAC_BYTES_PER_UPDATE
         wl = "SoftActorCritic (SAC-v1) on synthetic replay (1e6 transitions/agent), obs=3 act=1 l1=l2=128 batch=100"
+    elif algo == "ddpg_separate":
+        # actor_network.py / critic_network.py as two networks (json key `network: separate`), on the MFMA
+        # kernel since round 3; priced with the hydra network's 73.2 MFLOP (the second first layer adds < 1 %)
+        from rlcontrol_amd.hip_ddpg import DDPGPopulation, init_params
+        pop = DDPGPopulation(NA, S, A_DIM, H, H, H, B, REPLAY_N, 0.01, [-1, -1, -8], [1, 1, 8], [-2.0], [2.0], 1e-3, 1e-2,
+                             seeds=seeds, device=device, separate_networks=True)
+        for i in range(NA):
+            pop.set_params(i, init_params(S, A_DIM, H, H, H, int(seeds[i]), "input_norm", True))
+        host = synthetic_pendulum_replay(REPLAY_N, 0)
+        flop, byts = FLOP_PER_UPDATE, BYTES_PER_UPDATE + 2 * (S * H + H) * 4 * 4 * 2.0
+        wl = "DDPG with separate actor / critic networks on synthetic Pendulum-shaped replay, obs=3 act=1 200/200/200 batch=100"
     elif algo == "kl":
         from rlcontrol_amd.hip_kl import KLPopulation, init_params
         L = KL_SHAPE["L"]
@@ -317,7 +329,7 @@ def main():
                          "MAX all-reduce and all-gather then go through RCCL -- the one-GPU rehearsal of --gpus 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="skip the SAC / NAF sub-records")
-    ap.add_argument("--side-only", default="", choices=["", "sac", "naf", "kl"],
+    ap.add_argument("--side-only", default="", choices=["", "sac", "naf", "kl", "ddpg_separate"],
                     help="profiling helper: run ONLY that sub-record (no DDPG headline) and print its JSON")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-records", type=int, default=REPLAY_N)
@@ -420,7 +432,7 @@ def main():
         if world == 1 and not args.no_side_records:
             # BASELINE configs[2], [3] on the same box, same agent count and replay size (extra keys; `value` is DDPG)
             # the same launch length as the headline: U x steps = 6,400 timed updates per agent by default
-            for algo in ("sac", "naf", "kl"):
+            for algo in ("sac", "naf", "kl", "ddpg_separate"):
                 out[algo] = side_record(algo, NA, U, args.steps, args.warmup, torch, local_rank)
         print(json.dumps(out))
     if dist is not None:

@@ -15,7 +15,7 @@ RLC_FOR_V2(RLC_DECL2)
 static inline int mt_for(int B) { return B <= 32 ? 2 : (B <= 64 ? 4 : (B <= 112 ? 7 : 8)); }
 
 bool rlc_mfma_supported(const RlcDims& d) {
-    if (d.norm || d.sep) return false;      // layer norm / separate networks: the any-shape kernel (ddpg_generic.hip)
+    if (d.norm) return false;               // layer norm: the any-shape kernel (ddpg_generic.hip)
     auto okdim = [](int h) { return h >= 16 && h <= 256 && (h % 4) == 0; };
     if (!(okdim(d.H1) && okdim(d.HA) && okdim(d.HC))) return false;
     if (d.S < 1 || d.S > SMAX) return false;

@@ -93,7 +93,11 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
     u.L.hbuf = L.hbuf; u.L.mask = L.mask; u.L.xbuf = L.xbuf;
     const int tid = u.tid, S = d.S, H1 = d.H1, HA = d.HA, HC = d.HC, B = d.B;
     const int agent = first_agent + blockIdx.x;
-    constexpr bool fuse_fwd = FUSE;      // the launcher picks FUSE when HA == HC
+    constexpr bool fuse_fwd = FUSE;      // the launcher picks FUSE when HA == HC and the networks share their first layer
+    // `network: separate` (actor_network.py:73-96 / critic_network.py:77-99): the critic has a first layer of its own
+    // (d.oWc1 / d.obc1; in the hydra network they alias d.oW1 / d.ob1), stepped and Polyak-averaged by the critic's Adam
+    // alone.  The activation image then has to change hands: six first-layer passes per update instead of three.
+    const bool sep = d.sep != 0;         // workgroup-uniform
 
     float* th = dv.theta + (size_t)agent * d.Ppad;
     float* tt = dv.theta_t + (size_t)agent * d.Ppad;
@@ -235,6 +239,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #pragma unroll
                 for (int i = 0; i < NTW; i++) acc[mt][i] = acc2[mt][i];
         } else {
+            if (sep) {
+                u.trunk(tt + d.oWc1, tt + d.obc1, L.x2);      // the target critic's own first layer
+                lds_barrier();
+            }
             u.template fwd_gemm<true>(acc, tt + d.oWc2, HC, H1);
         }
         u.template bias_relu<AD>(acc, tt + d.obc2, HC, L.aout, tt + d.oWc2, d.arow0);
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #ifdef RLC_W1_STAGE
         u.trunk((const lds_f32*)L.w1o, (const lds_f32*)(L.w1o + S * H1), L.x);
 #else
-        u.trunk(th + d.oW1, th + d.ob1, L.x);
+        u.trunk(th + d.oWc1, th + d.obc1, L.x);           // the critic's first layer (= the shared trunk in the hydra network)
 #endif
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < HC ? th[d.oWc3 + n] : 0.0f;
         lds_barrier();
@@ -315,7 +323,9 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #ifdef RLC_W1_STAGE
         u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f, L.x, NoExtra{}, L.w1o);   // step 4 reads the stepped trunk
 #else
-        u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oW1, d.ob1, tap_gc, nullptr, 0.0f, L.x);
+        // hydra: the trunk's target copy follows in the actor step; separate networks: the critic's first layer is
+        // Polyak-averaged here, by the only optimizer that owns it
+        u.trunk_grad_adam(acc, th, m_c, v_c, alpha_c, d.oWc1, d.obc1, tap_gc, sep ? tt : nullptr, tau, L.x);
 #endif
         STAMP();
         // dWc2 = [h1|a]^T . dg2 with Adam + Polyak in the epilogue
@@ -403,6 +413,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #pragma unroll
                 for (int i = 0; i < NTW; i++) acc[mt][i] = acc7[mt][i];
         } else {
+            if (sep) {
+                u.trunk(th + d.oWc1, th + d.obc1, L.x);       // the stepped critic's first layer at s
+                lds_barrier();
+            }
             u.fwd_gemm(acc, th + d.oWc2, HC, H1);
         }
         u.template bias_relu<AD>(acc, th + d.obc2, HC, L.aout, th + d.oWc2, d.arow0);
@@ -457,6 +471,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         const float alpha_a = adam_alpha(lr_a, pw[0], pw[1]);
         u.template bwd_gemm<AD, -2>(acc, th + d.oWa2, HA, H1, L.dz, L.wvec);
         lds_barrier();
+        if (sep) {
+            u.trunk(th + d.oW1, th + d.ob1, L.x);             // the actor's image again: its relu mask and the weight-gradient operand
+            lds_barrier();
+        }
         STAMP();
 #ifdef RLC_EARLY_PREFETCH
         u.template wgrad_prefetch<false, 1>(pre, HA, th + d.oWa2, m_a + d.oWa2, v_a + d.oWa2, tt + d.oWa2);
@@ -537,7 +555,7 @@ template <int MT, int AD>
 int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
              int grad_taps, hipStream_t st, const RlcRollout* rollout, int q8_first) {
 #ifndef RLC_DDPG_SEPARATE_FWD
-    if (dv.d.HA == dv.d.HC)
+    if (dv.d.HA == dv.d.HC && !dv.d.sep)
         return launch_tf<MT, AD, true>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);
 #endif
     return launch_tf<MT, AD, false>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);

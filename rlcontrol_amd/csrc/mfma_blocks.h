@@ -328,7 +328,10 @@ struct Blk {
                 bias[e] = live ? b1[k] : 0.0f;
             }
             const bool live4[4] = {4 * q < H1, 4 * q + 1 < H1, 4 * q + 2 < H1, 4 * q + 3 < H1};
-#pragma unroll 2
+#ifndef RLC_TRUNK_UNROLL
+#define RLC_TRUNK_UNROLL 2
+#endif
+#pragma unroll RLC_TRUNK_UNROLL
             for (int b = wave; b < MB; b += kWaves) {
                 const f32x4 x0 = *reinterpret_cast<const lds_f32x4*>(&xs[b * SMAX]);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};

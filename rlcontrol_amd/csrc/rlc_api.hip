@@ -220,7 +220,7 @@ int rlc_ddpg_create(const rlc_ddpg_config* cfg, rlc_handle** out) {
                          cfg->critic_l2_dim, cfg->batch_size, 0, cfg->norm_type, cfg->separate_networks);
     if (rlc_mfma_supported(dv.d))
         dv.d = rlc_make_dims(cfg->state_dim, cfg->action_dim, cfg->shared_l1_dim, cfg->actor_l2_dim,
-                             cfg->critic_l2_dim, cfg->batch_size, 1);
+                             cfg->critic_l2_dim, cfg->batch_size, 1, cfg->norm_type, cfg->separate_networks);
     dv.rep = h->rep;
     dv.n_agents = cfg->n_agents;
     dv.clip_state = cfg->clip_state;
@@ -767,6 +767,7 @@ int rlc_ddpg_set_split(rlc_handle* h, int32_t n_workgroups) {
     RLC_REQUIRE(!h->has_env, "the on-device experiment loop runs the one-workgroup kernels");
     if (n_workgroups == 1) { h->split_c = 1; return 0; }
     RLC_REQUIRE(pick_variant(h) == 2, "the split update is a variant of the MFMA kernel (these dimensions run the generic one)");
+    RLC_REQUIRE(!h->dv.d.sep, "latency mode is built for the hydra network (network: separate runs the one-workgroup kernels)");
     RLC_REQUIRE(rlc_split_mt(h->dv.d.B, n_workgroups) > 0, "batch_size %d does not fit %d workgroups of at most 64 rows",
                 h->dv.d.B, n_workgroups);
     hipDeviceProp_t prop;

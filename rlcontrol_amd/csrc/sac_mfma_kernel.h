@@ -105,6 +105,17 @@ __device__ inline float sac_blk_sum(float v, lds_f32* red) {
     return s;
 }
 
+// two block-wide sums in one pass (one exchange, three barriers instead of six)
+__device__ inline void sac_blk_sum2(float a, float b, lds_f32* red, float& sa, float& sb) {
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); b += __shfl_down(b, off, 64); }
+    lds_barrier();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = a; red[8 + (threadIdx.x >> 6)] = b; }
+    lds_barrier();
+    sa = 0.0f; sb = 0.0f;
+    for (int w = 0; w < kWaves; w++) { sa += red[w]; sb += red[8 + w]; }
+    lds_barrier();
+}
+
 template <int MT, int NTW, int AD>
 __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev dv, int first_agent, int n_updates,
                                                                        int source, const long long* host_idx,
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         u.template row_dot<false, 1>(accq, L2C, [&](int n, int) { return th[d.qW3 + n]; }, L.part_q);
         u.template store_masks<1, false>(accq, L2C);
         lds_barrier();
-        float part_lp = 0.0f, part_qp = 0.0f;
+        float part_lp = 0.0f, part_qp = 0.0f, part_lp2 = 0.0f;
         for (int b = tid; b < B; b += kThreads) {
             const float q = u.template part_sum<1>(L.part_q, b, 0) + th[d.qb3];
             const float qpi = u.template part_sum<1 + AD>(L.part_p, b, 0) + th[d.qb3];
@@ -300,10 +311,12 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             dv.tap_q[(size_t)agent * RLC_MAX_BATCH + b] = q;
             dv.tap_qpi[(size_t)agent * RLC_MAX_BATCH + b] = qpi;
             L.dout[b] = -((L.r[b] + L.g[b] * L.vt[b]) - q) * invB;                 // d q_loss / d q
-            part_lp += L.logp[b]; part_qp += qpi;
+            part_lp += L.logp[b]; part_qp += qpi; part_lp2 += L.logp[b] * L.logp[b];
         }
-        const float mean_logp = sac_blk_sum(part_lp, L.red) * invB;
-        const float mean_qpi = sac_blk_sum(part_qp, L.red) * invB;
+        float sum_lp, sum_qp;
+        sac_blk_sum2(part_lp, part_qp, L.red, sum_lp, sum_qp);
+        const float mean_logp = sum_lp * invB, mean_qpi = sum_qp * invB;
+        const float sum_lp2 = sac_blk_sum(part_lp2, L.red);       // for the v_loss tap below
         // pi seeds: d(alpha*mean(logp) - mean(Q(s,pi))) / d(mu_raw, log_std_pre)
         for (int it = tid; it < B * AD; it += kThreads) {
             const int b = it / AD, j = it % AD;
@@ -479,13 +492,12 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 L.dvs[b] = -(L.qpi[b] - alpha_ent * mean_logp - v) * invB;
                 const float e = (L.r[b] + L.g[b] * L.vt[b]) - L.q[b];
                 ql += e * e;
-                for (int j = 0; j < B; j++) {
-                    const float f = L.qpi[b] - alpha_ent * L.logp[j] - v;
-                    vl += f * f;
-                }
+                // sum_j (c - alpha logp[j])^2 over the [B, B] broadcast (Q9), c = q_pi[b] - v[b], in closed form from
+                // sum logp and sum logp^2 (the j-loop cost 3 us per update for a diagnostic tap)
+                const float cc = L.qpi[b] - v;
+                vl += (float)B * cc * cc - 2.0f * cc * alpha_ent * sum_lp + alpha_ent * alpha_ent * sum_lp2;
             }
-            ql = sac_blk_sum(ql, L.red);
-            vl = sac_blk_sum(vl, L.red);
+            sac_blk_sum2(ql, vl, L.red, ql, vl);
             if (tid == 0) {
                 dv.tap_loss[agent * 4 + 0] = alpha_ent * mean_logp - mean_qpi;
                 dv.tap_loss[agent * 4 + 1] = 0.5f * ql * invB;

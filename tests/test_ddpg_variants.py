@@ -112,9 +112,12 @@ def _pop(dims, B, norm, sep, n_agents=1, cap=512):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kernel", ["generic", "mfma"])
 @pytest.mark.parametrize("norm,sep", VARIANTS)
 @pytest.mark.parametrize("dims,B", SHAPES)
-def test_hip_variant_update_matches_oracle(hip_lib, dims, B, norm, sep):
+def test_hip_variant_update_matches_oracle(hip_lib, dims, B, norm, sep, kernel):
+    if kernel == "mfma" and norm:
+        pytest.skip("layer norm runs on the any-shape kernel only (DESIGN.md 9)")
     d = VDims(*dims, norm=norm, separate=sep)
     th = init_params(d, 2)
     rng = np.random.RandomState(1)
@@ -125,7 +128,10 @@ def test_hip_variant_update_matches_oracle(hip_lib, dims, B, norm, sep):
             th[off:off + k] += rng.uniform(-0.3, 0.3, k).astype(np.float32)
     smin, smax, amax = _bounds(dims[0], dims[1])
     pop = _pop(dims, B, norm, sep)
-    assert pop.P == P and pop.kernel_in_use() == "generic"            # the variants run on the any-shape kernel
+    # layer norm runs on the any-shape kernel; `network: separate` alone takes the MFMA kernel by default (round 3)
+    assert pop.P == P and pop.kernel_in_use() == ("generic" if norm else "mfma")
+    pop.set_kernel(kernel)
+    assert pop.kernel_in_use() == kernel
     from rlcontrol_amd.hip_ddpg import param_layout
     assert list(param_layout(*dims, "layer" if norm else "input_norm", sep)[0]) == list(lay)
     pop.enable_grad_taps(True)
