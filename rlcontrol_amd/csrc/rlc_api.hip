@@ -570,7 +570,7 @@ int rlc_ddpg_act_fetch(rlc_handle* h, int32_t first_agent, int32_t n, float* out
         // spin on the completion word the kernel stores after its actions (microseconds after the kernel ends; a stream
         // synchronisation wakes up tens of microseconds later); bounded, then the ordinary wait
         volatile int* flag = (volatile int*)(h->aq_host + h->aq_cap / sizeof(float) - 1);
-        for (long spin = 0; spin < 200000000L; spin++) {
+        for (long spin = 0; spin < 2000000L; spin++) {      // ~20 ms; a non-coherent mapping never shows the word: fall back
             if (*flag == h->aq_seq) { done = true; break; }
 #if defined(__x86_64__)
             __builtin_ia32_pause();
