@@ -66,6 +66,11 @@ class BaseAgent(object):
                 self.network_manager.update_from_replay(indices, next_state=next_state)
             else:
                 self.network_manager.update_from_replay(indices)
+            # the next step's minibatch indices, drawn while the GPU is busy (the next transition is stored unless the
+            # step is truncated: ReplayBuffer.presample undoes a wrong guess)
+            if hasattr(self.replay_buffer, "presample"):
+                self.replay_buffer.presample(self.batch_size, min(self.replay_buffer.get_size() + 1,
+                                                                  int(self.replay_buffer.buffer_size)))
 
     def reset(self):
         self.network_manager.reset()

@@ -123,11 +123,19 @@ __host__ __device__ inline size_t ksmem_carve(const RlcSacDims& d, int MT, int M
     L.hbuf = (lds_f32*)take(sizeof(float) * (MTX * 16 * LDH + 16));
     L.idx = (lds_i64*)take(sizeof(long long) * RLC_MAX_BATCH);
     L.mask = take((size_t)MB * KL_MSTRIDE);
-    L.part_h = (lds_f32*)take(sizeof(float) * kWaves * MB * 2);
-    L.part_q = (lds_f32*)take(sizeof(float) * kWaves * MTX * 16);
+    // the two partial buffers are never live together (a barrier separates every use of one from the next use of the
+    // other): one region of the larger size
+    {
+        const size_t bh = sizeof(float) * kWaves * MB * 2, bq = sizeof(float) * kWaves * MTX * 16;
+        L.part_h = (lds_f32*)take(bh > bq ? bh : bq);
+        L.part_q = L.part_h;
+    }
     L.wvec = (lds_f32*)take(sizeof(float) * 2 * 256);
-    lds_f32** ps[] = {&L.x, &L.x2, &L.xq, &L.xn};
+    // x (s) is a prefix of xq ([s, a]): the first-layer passes of pi and V read S columns of it and multiply the rest by
+    // zero weights, so the two share one array
+    lds_f32** ps[] = {&L.x2, &L.xq, &L.xn};
     for (auto p : ps) *p = (lds_f32*)take(sizeof(float) * MB * SMAX);
+    L.x = L.xq;
     // at more than two batch tiles the first-layer image of Q (MB x LDH floats: 90 KB at seven tiles) lives in the agent's
     // global scratch instead (kl_z1s_in_global): the node passes read two or three of its rows each, L1-resident
     L.z1s = kl_z1s_in_global(MT) ? nullptr : (lds_f32*)take(sizeof(float) * MB * LDH);

@@ -29,6 +29,7 @@ class ReplayBuffer(object):
         self.sampler_mode = sampler
         # same stream as RandomAccessQueue(maxlen, seed=random_seed).rng (custom_collections.py:15)
         self.sampler = DistinctIndexSampler(random_seed)
+        self._pre = None          # (RNG state before the draw, size it assumed, batch size, indices): presample()
 
     def add(self, state, action, reward, next_state, transition_gamma):
         self._pop.replay_add(self._agent, state, action, reward, next_state, transition_gamma)
@@ -36,12 +37,29 @@ class ReplayBuffer(object):
     def get_size(self):
         return self._pop.replay_size(self._agent)
 
+    def presample(self, batch_size, n_expected):
+        """Draw the indices of the NEXT sample_indices(batch_size) call now -- while the GPU works on the update just
+        launched -- assuming the buffer will hold n_expected transitions then.  The sampler's stream is the only user of
+        its RandomState, so drawing early changes nothing; if the guess turns out wrong (a truncated step stores
+        nothing, utils/replaybuffer.py / agents/base_agent.py:56-58) the draw is undone and made again."""
+        if self.sampler_mode != "reference" or n_expected < batch_size:
+            return
+        state = self.sampler.rng.get_state()
+        self._pre = (state, int(n_expected), int(batch_size),
+                     np.asarray(self.sampler.sample_n_k(int(n_expected), batch_size), dtype=np.int64))
+
     def sample_indices(self, batch_size):
         """k distinct logical positions (0 = oldest), reference RNG stream or device Philox."""
         n = self.get_size()
         assert n >= batch_size
         if self.sampler_mode == "device":
             return self._pop.replay_sample_indices(self._agent, batch_size)
+        pre, self._pre = self._pre, None
+        if pre is not None:
+            state, n_expected, k, idx = pre
+            if n_expected == n and k == batch_size:
+                return idx
+            self.sampler.rng.set_state(state)          # wrong guess: the stream goes back to where it was
         return np.asarray(self.sampler.sample_n_k(n, batch_size), dtype=np.int64)
 
     def sample_batch(self, batch_size):

@@ -102,3 +102,31 @@ def test_main_result_pickle_schema(tmp_path, monkeypatch):
     assert run["eval_episode_rewards"].shape == (5, 2)
     assert disk["experiment"]["agent"]["agent_name"] == "DDPG"
     assert disk["experiment_data"][1]["agent_params"]["actor_lr"] == 0.005
+
+
+def test_presampled_indices_follow_the_reference_stream():
+    """ReplayBuffer.presample draws the next minibatch early; a wrong guess of the buffer size (a truncated step stores
+    nothing) is undone: the index stream equals the plain sampler's, call for call."""
+    import numpy as np
+    from rlcontrol_amd.utils.replaybuffer import ReplayBuffer
+
+    class _Store(object):
+        def __init__(self):
+            self.n = 0
+
+        def replay_size(self, agent):
+            return self.n
+
+    plain_store, pre_store = _Store(), _Store()
+    plain = ReplayBuffer(10000, 5, store=(plain_store, 0))
+    pre = ReplayBuffer(10000, 5, store=(pre_store, 0))
+    rng = np.random.RandomState(0)
+    size = 40
+    for step in range(300):
+        stored = rng.rand() > 0.15                  # 15 % of the steps are "truncated": nothing is stored
+        size += 1 if stored else 0
+        plain_store.n = pre_store.n = size
+        a = plain.sample_indices(32)
+        b = pre.sample_indices(32)
+        assert np.array_equal(a, b), step
+        pre.presample(32, size + 1)                 # always guesses that the next transition will be stored
