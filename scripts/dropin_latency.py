@@ -79,12 +79,18 @@ def main():
     ap.add_argument("--skip", type=int, default=500)
     ap.add_argument("--tag", default="r02c")
     ap.add_argument("--only", default="", help="comma-separated agent names")
+    ap.add_argument("--batches", default="", help="comma-separated batch sizes (default: 32 and 100)")
+    ap.add_argument("--no-split", action="store_true", help="skip the latency-mode rows")
     a = ap.parse_args()
     res = {"steps_timed": a.steps - a.skip, "environment": "Pendulum-v0 (host numpy simulator)", "rows": []}
     cases = [(n, b, {}) for n in AGENTS for b in (32, 100)] + [("DDPG", b, {"hip_split": c}) for b, c in ((32, 2), (100, 7))] + \
             [(n, 32, {"hip_split": 8}) for n in ("ReverseKL", "ForwardKL")]
     if a.only:
         cases = [c for c in cases if c[0] in a.only.split(",")]
+    if a.batches:
+        cases = [c for c in cases if str(c[1]) in a.batches.split(",")]
+    if a.no_split:
+        cases = [c for c in cases if not c[2]]
     for name, batch, extra in cases:
         r = measure(name, batch, extra, a.steps, a.skip)
         r.update(agent=name, batch=batch, **extra)
