@@ -45,18 +45,23 @@ def _headers():
 
 def _units():
     units = [(os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o")), []) for s in PLAIN]
+    # seven-tile shapes also in their tail-of-four form (mfma_blocks.h, Blk's T4: batch 97..100)
+    t4 = lambda mt: ((0, ""), (1, "_t4")) if mt == 7 else ((0, ""),)
     for mt, ad in MFMA_VARIANTS:
-        units.append((os.path.join(CSRC, "ddpg_mfma_inst.hip"), os.path.join(OBJ, "ddpg_mfma_%d_%d.o" % (mt, ad)),
-                      ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
+        for flag, tag in t4(mt):
+            units.append((os.path.join(CSRC, "ddpg_mfma_inst.hip"), os.path.join(OBJ, "ddpg_mfma_%d_%d%s.o" % (mt, ad, tag)),
+                          ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad, "-DRLC_T4=%d" % flag]))
     for mt, ad in SPLIT_VARIANTS:
         units.append((os.path.join(CSRC, "ddpg_split_inst.hip"), os.path.join(OBJ, "ddpg_split_%d_%d.o" % (mt, ad)),
                       ["-DRLC_MT=%d" % mt, "-DRLC_AD=%d" % ad]))
     for mt, ntw, ad in SAC_VARIANTS:
-        units.append((os.path.join(CSRC, "sac_mfma_inst.hip"), os.path.join(OBJ, "sac_mfma_%d_%d_%d.o" % (mt, ntw, ad)),
-                      ["-DRLC_MT=%d" % mt, "-DRLC_NTW=%d" % ntw, "-DRLC_AD=%d" % ad]))
+        for flag, tag in t4(mt):
+            units.append((os.path.join(CSRC, "sac_mfma_inst.hip"), os.path.join(OBJ, "sac_mfma_%d_%d_%d%s.o" % (mt, ntw, ad, tag)),
+                          ["-DRLC_MT=%d" % mt, "-DRLC_NTW=%d" % ntw, "-DRLC_AD=%d" % ad, "-DRLC_T4=%d" % flag]))
     for mt, ntw, ad in NAF_VARIANTS:
-        units.append((os.path.join(CSRC, "naf_mfma_inst.hip"), os.path.join(OBJ, "naf_mfma_%d_%d_%d.o" % (mt, ntw, ad)),
-                      ["-DRLC_MT=%d" % mt, "-DRLC_NTW=%d" % ntw, "-DRLC_AD=%d" % ad]))
+        for flag, tag in t4(mt):
+            units.append((os.path.join(CSRC, "naf_mfma_inst.hip"), os.path.join(OBJ, "naf_mfma_%d_%d_%d%s.o" % (mt, ntw, ad, tag)),
+                          ["-DRLC_MT=%d" % mt, "-DRLC_NTW=%d" % ntw, "-DRLC_AD=%d" % ad, "-DRLC_T4=%d" % flag]))
     return units
 
 

@@ -11,6 +11,15 @@
 #define RLC_DECL2(M, A_) \
     int rlc_mfma_launch_##M##_##A_(const RlcDev&, int, int, int, int, const long long*, int, hipStream_t, const RlcRollout*, int);
 RLC_FOR_V2(RLC_DECL2)
+// tail-of-four variants (compiled for the seven-tile shapes only: batch 97..100)
+#ifdef RLC_ONLY_7_1
+#define RLC_FOR_T4(X) X(7, 1)
+#else
+#define RLC_FOR_T4(X) X(7, 1) X(7, 2)
+#endif
+#define RLC_DECLT4(M, A_) \
+    int rlc_mfma_launch_t4_##M##_##A_(const RlcDev&, int, int, int, int, const long long*, int, hipStream_t, const RlcRollout*, int);
+RLC_FOR_T4(RLC_DECLT4)
 
 static inline int mt_for(int B) { return B <= 32 ? 2 : (B <= 64 ? 4 : (B <= 112 ? 7 : 8)); }
 
@@ -30,6 +39,12 @@ int rlc_launch_ddpg_update_mfma(const RlcDev& dv, int first_agent, int n_agents,
     RLC_REQUIRE(rlc_mfma_supported(dv.d), "MFMA kernel does not support these dimensions");
     RLC_REQUIRE(dv.d.blocked, "the MFMA kernel reads tile-blocked weights (rlc_ddpg_set_kernel re-packs them)");
     const int mt = mt_for(dv.d.B);
+#define RLC_CASET4(M, A_)                                           \
+    if (mt == M && dv.d.A == A_ && rlc_tail4_enabled(dv.d.B, M))    \
+        return rlc_mfma_launch_t4_##M##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, \
+                                             q8_first);
+    RLC_FOR_T4(RLC_CASET4)
+#undef RLC_CASET4
 #define RLC_CASE2(M, A_)          \
     if (mt == M && dv.d.A == A_)  \
         return rlc_mfma_launch_##M##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, \

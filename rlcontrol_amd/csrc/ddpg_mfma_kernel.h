@@ -76,13 +76,14 @@ __host__ __device__ inline size_t smem_carve(const RlcDims& d, int MT, lds_u8* b
 
 // FUSE: the actor's and the critic's second layers have one width: their hidden contractions over one trunk image run
 // as ONE k-loop (target pair, online pair)
-template <int MT, int AD, bool FUSE>
+// T4: the minibatch ends within the first four rows of its last tile (mfma_blocks.h, Blk's T4; the launcher checks it)
+template <int MT, int AD, bool FUSE, bool T4>
 __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev dv, int first_agent, int n_updates,
                                                                         int source, const long long* host_idx,
                                                                         int grad_taps, const RlcRollout* rollout,
                                                                         int q8_first) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using U = Blk<MT, NTW, MSTRIDE>;
+    using U = Blk<MT, NTW, MSTRIDE, false, false, T4>;
     constexpr int MB = U::MB;
     const RlcDims d = dv.d;
     U u;
@@ -534,12 +535,13 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
 #endif
 }
 
-template <int MT, int AD, bool FUSE>
+template <int MT, int AD, bool FUSE, bool T4>
 int launch_tf(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
               int grad_taps, hipStream_t st, const RlcRollout* rollout, int q8_first) {
     const size_t lds = smem_carve(dv.d, MT, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "MFMA DDPG kernel needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = rlc_ddpg_update_mfma_kernel<MT, AD, FUSE>;
+    RLC_REQUIRE(!T4 || rlc_tail4(dv.d.B, MT), "tail-of-four kernel launched for batch %d", dv.d.B);
+    auto kern = rlc_ddpg_update_mfma_kernel<MT, AD, FUSE, T4>;
     static bool attr_set = false;
     if (!attr_set) {
         RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -551,14 +553,14 @@ int launch_tf(const RlcDev& dv, int first_agent, int n_agents, int n_updates, in
     return 0;
 }
 
-template <int MT, int AD>
+template <int MT, int AD, bool T4>
 int launch_t(const RlcDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
              int grad_taps, hipStream_t st, const RlcRollout* rollout, int q8_first) {
 #ifndef RLC_DDPG_SEPARATE_FWD
     if (dv.d.HA == dv.d.HC && !dv.d.sep)
-        return launch_tf<MT, AD, true>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);
+        return launch_tf<MT, AD, true, T4>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);
 #endif
-    return launch_tf<MT, AD, false>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);
+    return launch_tf<MT, AD, false, T4>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout, q8_first);
 }
 
 }  // namespace

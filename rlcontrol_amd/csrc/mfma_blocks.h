@@ -25,6 +25,7 @@
 // Big matrices use the TILE-BLOCKED layout of rlc_common.h (rlc_blk_index): every instruction of the weight
 // streams touches 1 KB contiguous.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "rlc_common.h"
@@ -155,6 +156,12 @@ __device__ __forceinline__ void st_target(float* p, f32x4 v) {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4 x 4 outer products, block l / 4 of the wave; lane l gives row l % 4 of
+// its block's A column and column l % 4 of its B row, and receives column l % 4 of the block's 4 x 4 result (one row per
+// register).  15 cycles of the matrix pipe against the 16x16x4's 32 (scripts/micro/mfma4x4_tail.hip): see Blk's T4.
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
 
 // sum over the 16 lanes that share lane>>4 (rotate-reduce with DPP row_ror: every lane gets the sum)
 template <int ROR>
@@ -174,6 +181,14 @@ __device__ __forceinline__ float col4_sum(float x) {
     x += __shfl_xor(x, 16, 64);
     x += __shfl_xor(x, 32, 64);
     return x;
+}
+
+// Blk's T4 applies when the minibatch ends within the first four rows of its last 16-row tile
+__host__ __device__ inline bool rlc_tail4(int B, int MT) { return B > 16 * (MT - 1) && B <= 16 * (MT - 1) + 4; }
+// ... and the dispatchers take the tail-of-four instantiations then, unless RLC_NO_TAIL4=1 (A/B switch, read once)
+inline bool rlc_tail4_enabled(int B, int MT) {
+    static const bool off = [] { const char* e = getenv("RLC_NO_TAIL4"); return e && e[0] == '1'; }();
+    return !off && rlc_tail4(B, MT);
 }
 
 __host__ __device__ inline int ldh_for(int H1) {
@@ -218,9 +233,16 @@ struct HeadExtra {
 // (hydra_ddpg_network.py:29, naf_network.py:62-63)
 // TADAM: torch.optim.Adam's step (the KL agents): the caller folds sqrt(1 - b2^t) into alpha and sets adam_eps =
 // 1e-8 * sqrt(1 - b2^t) (see kl_generic.hip); otherwise TF's ApplyAdam with its constant epsilon
-template <int MT, int NTW, int MSTRIDE, bool LERP = false, bool TADAM = false>
+// T4: the minibatch ends within the first FOUR rows of its last 16-row tile (batch 100 = six tiles + 4 rows).  The
+// k-loops then run that tile through v_mfma_f32_4x4x1_16b_f32 instead of a 16x16x4 whose other twelve rows are padding:
+// with the very same B register (lane 16g + c: the weight of k = 4g + s, column c) and the A value of row c & 3
+// instead of row c, block (g, c / 4) of the instruction accumulates rows 0..3 x columns 4(c/4)..+3 over the k's of lane
+// group g; a butterfly over g after the loop (tail_finish) completes the sum, and lanes g == 0 hold rows 0..3 of column
+// c -- exactly what they hold of a 16x16x4 accumulator, so every epilogue is unchanged (lanes g > 0 = rows 4..15 = 0).
+template <int MT, int NTW, int MSTRIDE, bool LERP = false, bool TADAM = false, bool T4 = false>
 struct Blk {
     static constexpr int MB = MT * 16;
+    static constexpr int TROW = 16 * (MT - 1);          // first row of the last batch tile
 
     __device__ __forceinline__ static float polyak(float t, float w, float tau) {
         return LERP ? (1.0f - tau) * t + tau * w : t + tau * (w - t);
@@ -275,8 +297,22 @@ struct Blk {
     }
     static constexpr int MXS = (MT + 3) / 4;            // batch tiles of a split tile per wave (at most)
     __device__ __forceinline__ bool split_mode(int NT) const { return NTW == 2 && NT == 13 && L.xbuf != nullptr; }
-    // batch-tile range [lo, hi) of wave 4+s's share of the split tile
-    __device__ __forceinline__ static int share_lo(int s) { return (s * MT + 3) / 4; }
+    // batch-tile range [lo, hi) of wave 4+s's share of the split tile.  T4: waves 4-6 take MXS full tiles each, wave 7
+    // the four-row tail alone (XMODE 2 of the loops)
+    static_assert(!T4 || NTW != 2 || 3 * MXS == MT - 1, "T4 shares of the split tile: three waves of MXS full tiles + the tail");
+    __device__ __forceinline__ static int share_lo(int s) { return T4 ? (s < 4 ? s * MXS : MT) : (s * MT + 3) / 4; }
+    // XMODE of the k-loops: 0 = the wave's own tiles only, 1 = + batch tiles [xm0, xm0 + MXS) of the split tile,
+    // 2 = + the split tile's four-row tail (T4)
+    __device__ __forceinline__ int xmode_of_wave() const { return (T4 && wave == 7) ? 2 : 1; }
+    // complete a T4 tail accumulator: sum the four lane groups' partial products; rows 4..15 of the tile are zero
+    __device__ __forceinline__ f32x4 tail_finish(f32x4 v) const {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            v[r] += __shfl_xor(v[r], 16, 64);
+            v[r] += __shfl_xor(v[r], 32, 64);
+        }
+        return g == 0 ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---------------------------------------------------------------------------------------
     // hbuf[b][k] = relu(b1[k] + sum_i xs[b][i] W1[i][k])   (rows >= B and columns >= H1 zeroed)
@@ -362,42 +398,51 @@ struct Blk {
     // loop unrolled by two, so there are no register-rotation moves either: per chunk a wave issues
     // MT ds_read_b128 + 4*NOWN global_load_dword + 4*MT*NOWN MFMAs and little else.
     // ---------------------------------------------------------------------------------------
-    // XTRA: besides its NOWN full tiles the wave computes batch tiles [xm0, xm0 + xnm) of the split tile xt into accx
-    template <int NOWN, bool XTRA, bool STREAM = false>
+    // XMODE (see share_lo): besides its NOWN tiles the wave computes its share of the split tile xt into accx
+    template <int NOWN, int XMODE, bool STREAM = false>
     __device__ __forceinline__ void fwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NT, int KB, bool tail8,
                                              f32x4 (&accx)[MXS], int xt, int xm0) {
+        constexpr bool XTRA = XMODE != 0;
+        constexpr int NX = XMODE == 2 ? 1 : MXS;                    // slots of accx in use
         const int lofs = ((((c >> 2) << 4) + 4 * g) << 2) + (c & 3);
         const float* wp = W + ((size_t)tile0() << 8) + lofs;
         const int tst = tstep() << 8;
         const size_t wstep = (size_t)NT << 8;                       // floats between block rows
         const lds_f32* ap = L.hbuf + c * LDH + 4 * g;
+        const lds_f32* apt = L.hbuf + (TROW + (c & 3)) * LDH + 4 * g;      // T4: the tail tile's A rows
+        auto arow = [&](int mt) { return (T4 && mt == MT - 1) ? apt : ap + 16 * mt * LDH; };
         f32x4 a0[MT], a1[MT];
         float b0[NOWN][4], b1[NOWN][4];
+        f32x4 tq[NOWN];                                             // T4: the tail tile's 4x4x1 accumulators
+#pragma unroll
+        for (int i = 0; i < NOWN; i++) tq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the split tile's share: its own A fragments (the batch tiles are a run-time range) and B fragment
         const float* wpx = W + ((size_t)xt << 8) + lofs;
         const lds_f32* apx = ap + 16 * xm0 * LDH;
-        f32x4 ax0[MXS], ax1[MXS];
+        auto xrow = [&](int m) { return XMODE == 2 ? apt : apx + 16 * (xm0 + m < MT ? m : 0) * LDH; };
+        f32x4 ax0[NX], ax1[NX];
         float bx0[4], bx1[4];
-        auto loadX = [&](f32x4 (&da)[MXS], float (&db)[4], int ch) {
+        auto loadX = [&](f32x4 (&da)[NX], float (&db)[4], int ch) {
             if (XTRA) {
 #pragma unroll
-                for (int m = 0; m < MXS; m++)      // a share shorter than MXS repeats its first tile (result unused)
-                    da[m] = *reinterpret_cast<const lds_f32x4*>(apx + 16 * (xm0 + m < MT ? m : 0) * LDH + 16 * ch);
+                for (int m = 0; m < NX; m++)       // a share shorter than MXS repeats its first tile (result unused)
+                    da[m] = *reinterpret_cast<const lds_f32x4*>(xrow(m) + 16 * ch);
 #pragma unroll
                 for (int s2 = 0; s2 < 4; s2++) db[s2] = ld_w<STREAM>(&wpx[(size_t)ch * wstep + 4 * s2]);
             }
         };
-        auto macX = [&](const f32x4 (&da)[MXS], const float (&db)[4]) {
+        auto macX = [&](const f32x4 (&da)[NX], const float (&db)[4]) {
             if (XTRA) {
 #pragma unroll
                 for (int s2 = 0; s2 < 4; s2++)
 #pragma unroll
-                    for (int m = 0; m < MXS; m++) accx[m] = mfma16(da[m][s2], db[s2], accx[m]);
+                    for (int m = 0; m < NX; m++)
+                        accx[m] = XMODE == 2 ? mfma4(da[m][s2], db[s2], accx[m]) : mfma16(da[m][s2], db[s2], accx[m]);
             }
         };
         auto loadA = [&](f32x4 (&dst)[MT], int ch) {
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const lds_f32x4*>(ap + 16 * mt * LDH + 16 * ch);
+            for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const lds_f32x4*>(arow(mt) + 16 * ch);
         };
         auto loadB = [&](float (&dst)[NOWN][4], int ch) {
 #pragma unroll
@@ -411,7 +456,10 @@ struct Blk {
 #pragma unroll
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(a[mt][s], b[i][s], acc[mt][i]);
+                    for (int mt = 0; mt < MT; mt++) {
+                        if (T4 && mt == MT - 1) tq[i] = mfma4(a[mt][s], b[i][s], tq[i]);
+                        else acc[mt][i] = mfma16(a[mt][s], b[i][s], acc[mt][i]);
+                    }
         };
         loadB(b0, 0);
         loadA(a0, 0);
@@ -429,8 +477,8 @@ struct Blk {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4 * NOWN, 0);      // MFMA
             }
             if (XTRA) {
-                __builtin_amdgcn_sched_group_barrier(0x100, MXS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MXS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NX, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * NX, 0);
             }
         };
         for (; ch + 2 <= KB; ch += 2) {
@@ -452,7 +500,7 @@ struct Blk {
         if (tail8) {
             // K = 16 KB + 8: the last 8 k's in TWO steps instead of a zero-padded chunk of four -- lane group g takes
             // k = 16 KB + 2g + s (an 8-byte read of hbuf, two weight dwords per tile)
-            const lds_f32* at = L.hbuf + c * LDH + 16 * KB + 2 * g;
+            const int kofs = 16 * KB + 2 * g - 4 * g;              // relative to the chunk pointers (which carry + 4g)
             const int tofs = ((((c >> 2) << 4) + 2 * g) << 2) + (c & 3);
             const float* wt = W + ((size_t)tile0() << 8) + (size_t)KB * wstep + tofs;
             float bt[NOWN][2];
@@ -463,22 +511,31 @@ struct Blk {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 av[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) av[mt] = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * mt * LDH);
+            for (int mt = 0; mt < MT; mt++) av[mt] = *reinterpret_cast<const RLC_LDS f32x2*>(arow(mt) + kofs);
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+                    for (int mt = 0; mt < MT; mt++) {
+                        if (T4 && mt == MT - 1) tq[i] = mfma4(av[mt][s2], bt[i][s2], tq[i]);
+                        else acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+                    }
             if (XTRA) {
                 const float* wtx = W + ((size_t)xt << 8) + (size_t)KB * wstep + tofs;
 #pragma unroll
-                for (int m = 0; m < MXS; m++) {
-                    const f32x2 avx = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * (xm0 + m < MT ? xm0 + m : xm0) * LDH);
+                for (int m = 0; m < NX; m++) {
+                    const f32x2 avx = *reinterpret_cast<const RLC_LDS f32x2*>(xrow(m) + kofs);
 #pragma unroll
-                    for (int s2 = 0; s2 < 2; s2++) accx[m] = mfma16(avx[s2], wtx[4 * s2], accx[m]);
+                    for (int s2 = 0; s2 < 2; s2++)
+                        accx[m] = XMODE == 2 ? mfma4(avx[s2], wtx[4 * s2], accx[m]) : mfma16(avx[s2], wtx[4 * s2], accx[m]);
                 }
             }
+        }
+        if constexpr (T4) {
+#pragma unroll
+            for (int i = 0; i < NOWN; i++) acc[MT - 1][i] += tail_finish(tq[i]);
+            if constexpr (XMODE == 2) accx[0] = tail_finish(accx[0]);
         }
     }
 
@@ -525,13 +582,14 @@ struct Blk {
             if (split_mode(NT)) {                  // workgroup-uniform
 #pragma unroll
                 for (int m = 0; m < MXS; m++) accx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (wave >= 4) fwd_loop<1, true, STREAM>(acc, W, NT, KB, tail8, accx, NT - 1, share_lo(wave - 4));
-                else fwd_loop<2, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
+                if (T4 && wave == 7) fwd_loop<1, T4 ? 2 : 1, STREAM>(acc, W, NT, KB, tail8, accx, NT - 1, share_lo(3));
+                else if (wave >= 4) fwd_loop<1, 1, STREAM>(acc, W, NT, KB, tail8, accx, NT - 1, share_lo(wave - 4));
+                else fwd_loop<2, 0, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
                 collect_split<false>(acc, accx);
-            } else if (nown >= 2) fwd_loop<2, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
-            else if (nown == 1) fwd_loop<1, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
+            } else if (nown >= 2) fwd_loop<2, 0, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
+            else if (nown == 1) fwd_loop<1, 0, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
         } else {
-            if (nown >= 1) fwd_loop<1, false, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
+            if (nown >= 1) fwd_loop<1, 0, STREAM>(acc, W, NT, KB, tail8, accx, 0, 0);
         }
 #ifdef RLC_STAMPS
         if (lane == 0 && stamp_buf) stamp_buf[48 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles
@@ -545,10 +603,12 @@ struct Blk {
     // registers across the other GEMM's loop (where the compiler spilled it: NAF 224 VGPRs = 0.6 MB of scratch traffic
     // per update).  Same structure and pinning as fwd_loop; summation order per output element unchanged.
     // ---------------------------------------------------------------------------------------
-    template <int NOWN, bool XTRA, bool STREAM = false>
+    template <int NOWN, int XMODE, bool STREAM = false>
     __device__ __forceinline__ void fwd_loop2(f32x4 (&accA)[MT][NTW], f32x4 (&accB)[MT][NTW], const float* WA, const float* WB,
                                               int NT, int KB, bool tail8, f32x4 (&accxA)[MXS], f32x4 (&accxB)[MXS], int xt,
                                               int xm0) {
+        constexpr bool XTRA = XMODE != 0;
+        constexpr int NX = XMODE == 2 ? 1 : MXS;
         const int lofs = ((((c >> 2) << 4) + 4 * g) << 2) + (c & 3);
         const size_t t0 = ((size_t)tile0() << 8) + lofs;
         const float* wpA = WA + t0;
@@ -556,19 +616,24 @@ struct Blk {
         const int tst = tstep() << 8;
         const size_t wstep = (size_t)NT << 8;
         const lds_f32* ap = L.hbuf + c * LDH + 4 * g;
+        const lds_f32* apt = L.hbuf + (TROW + (c & 3)) * LDH + 4 * g;      // T4: the tail tile's A rows
+        auto arow = [&](int mt) { return (T4 && mt == MT - 1) ? apt : ap + 16 * mt * LDH; };
         f32x4 a0[MT], a1[MT];
         float b0[2][NOWN][4], b1[2][NOWN][4];
+        f32x4 tqA[NOWN], tqB[NOWN];                                        // T4: the tail tile's 4x4x1 accumulators
+#pragma unroll
+        for (int i = 0; i < NOWN; i++) { tqA[i] = f32x4{0.f, 0.f, 0.f, 0.f}; tqB[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const size_t tx = ((size_t)xt << 8) + lofs;
         const float* wpxA = WA + tx;
         const float* wpxB = WB + tx;
         const lds_f32* apx = ap + 16 * xm0 * LDH;
-        f32x4 ax0[MXS], ax1[MXS];
+        auto xrow = [&](int m) { return XMODE == 2 ? apt : apx + 16 * (xm0 + m < MT ? m : 0) * LDH; };
+        f32x4 ax0[NX], ax1[NX];
         float bx0[2][4], bx1[2][4];
-        auto loadX = [&](f32x4 (&da)[MXS], float (&db)[2][4], int ch) {
+        auto loadX = [&](f32x4 (&da)[NX], float (&db)[2][4], int ch) {
             if (XTRA) {
 #pragma unroll
-                for (int m = 0; m < MXS; m++)
-                    da[m] = *reinterpret_cast<const lds_f32x4*>(apx + 16 * (xm0 + m < MT ? m : 0) * LDH + 16 * ch);
+                for (int m = 0; m < NX; m++) da[m] = *reinterpret_cast<const lds_f32x4*>(xrow(m) + 16 * ch);
 #pragma unroll
                 for (int s2 = 0; s2 < 4; s2++) {
                     db[0][s2] = ld_w<STREAM>(&wpxA[(size_t)ch * wstep + 4 * s2]);
@@ -576,20 +641,25 @@ struct Blk {
                 }
             }
         };
-        auto macX = [&](const f32x4 (&da)[MXS], const float (&db)[2][4]) {
+        auto macX = [&](const f32x4 (&da)[NX], const float (&db)[2][4]) {
             if (XTRA) {
 #pragma unroll
                 for (int s2 = 0; s2 < 4; s2++)
 #pragma unroll
-                    for (int m = 0; m < MXS; m++) {
-                        accxA[m] = mfma16(da[m][s2], db[0][s2], accxA[m]);
-                        accxB[m] = mfma16(da[m][s2], db[1][s2], accxB[m]);
+                    for (int m = 0; m < NX; m++) {
+                        if (XMODE == 2) {
+                            accxA[m] = mfma4(da[m][s2], db[0][s2], accxA[m]);
+                            accxB[m] = mfma4(da[m][s2], db[1][s2], accxB[m]);
+                        } else {
+                            accxA[m] = mfma16(da[m][s2], db[0][s2], accxA[m]);
+                            accxB[m] = mfma16(da[m][s2], db[1][s2], accxB[m]);
+                        }
                     }
             }
         };
         auto loadA = [&](f32x4 (&dst)[MT], int ch) {
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const lds_f32x4*>(ap + 16 * mt * LDH + 16 * ch);
+            for (int mt = 0; mt < MT; mt++) dst[mt] = *reinterpret_cast<const lds_f32x4*>(arow(mt) + 16 * ch);
         };
         auto loadB = [&](float (&dst)[2][NOWN][4], int ch) {
 #pragma unroll
@@ -607,8 +677,13 @@ struct Blk {
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
-                        accA[mt][i] = mfma16(a[mt][s], b[0][i][s], accA[mt][i]);
-                        accB[mt][i] = mfma16(a[mt][s], b[1][i][s], accB[mt][i]);
+                        if (T4 && mt == MT - 1) {
+                            tqA[i] = mfma4(a[mt][s], b[0][i][s], tqA[i]);
+                            tqB[i] = mfma4(a[mt][s], b[1][i][s], tqB[i]);
+                        } else {
+                            accA[mt][i] = mfma16(a[mt][s], b[0][i][s], accA[mt][i]);
+                            accB[mt][i] = mfma16(a[mt][s], b[1][i][s], accB[mt][i]);
+                        }
                     }
         };
         loadB(b0, 0);
@@ -623,8 +698,8 @@ struct Blk {
                 __builtin_amdgcn_sched_group_barrier(0x008, 8 * NOWN, 0);      // MFMA
             }
             if (XTRA) {
-                __builtin_amdgcn_sched_group_barrier(0x100, MXS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 8 * MXS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, NX, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NX, 0);
             }
         };
         for (; ch + 2 <= KB; ch += 2) {
@@ -644,7 +719,7 @@ struct Blk {
         }
         if (ch < KB) { mac(a0, b0); macX(ax0, bx0); }
         if (tail8) {
-            const lds_f32* at = L.hbuf + c * LDH + 16 * KB + 2 * g;
+            const int kofs = 16 * KB + 2 * g - 4 * g;              // relative to the chunk pointers (which carry + 4g)
             const int tofs = ((((c >> 2) << 4) + 2 * g) << 2) + (c & 3);
             const size_t tb = ((size_t)tile0() << 8) + (size_t)KB * wstep + tofs;
             float bt[2][NOWN][2];
@@ -658,28 +733,46 @@ struct Blk {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 av[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) av[mt] = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * mt * LDH);
+            for (int mt = 0; mt < MT; mt++) av[mt] = *reinterpret_cast<const RLC_LDS f32x2*>(arow(mt) + kofs);
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
                     for (int mt = 0; mt < MT; mt++) {
-                        accA[mt][i] = mfma16(av[mt][s2], bt[0][i][s2], accA[mt][i]);
-                        accB[mt][i] = mfma16(av[mt][s2], bt[1][i][s2], accB[mt][i]);
+                        if (T4 && mt == MT - 1) {
+                            tqA[i] = mfma4(av[mt][s2], bt[0][i][s2], tqA[i]);
+                            tqB[i] = mfma4(av[mt][s2], bt[1][i][s2], tqB[i]);
+                        } else {
+                            accA[mt][i] = mfma16(av[mt][s2], bt[0][i][s2], accA[mt][i]);
+                            accB[mt][i] = mfma16(av[mt][s2], bt[1][i][s2], accB[mt][i]);
+                        }
                     }
             if (XTRA) {
                 const size_t txb = ((size_t)xt << 8) + (size_t)KB * wstep + tofs;
 #pragma unroll
-                for (int m = 0; m < MXS; m++) {
-                    const f32x2 avx = *reinterpret_cast<const RLC_LDS f32x2*>(at + 16 * (xm0 + m < MT ? xm0 + m : xm0) * LDH);
+                for (int m = 0; m < NX; m++) {
+                    const f32x2 avx = *reinterpret_cast<const RLC_LDS f32x2*>(xrow(m) + kofs);
 #pragma unroll
                     for (int s2 = 0; s2 < 2; s2++) {
-                        accxA[m] = mfma16(avx[s2], WA[txb + 4 * s2], accxA[m]);
-                        accxB[m] = mfma16(avx[s2], WB[txb + 4 * s2], accxB[m]);
+                        if (XMODE == 2) {
+                            accxA[m] = mfma4(avx[s2], WA[txb + 4 * s2], accxA[m]);
+                            accxB[m] = mfma4(avx[s2], WB[txb + 4 * s2], accxB[m]);
+                        } else {
+                            accxA[m] = mfma16(avx[s2], WA[txb + 4 * s2], accxA[m]);
+                            accxB[m] = mfma16(avx[s2], WB[txb + 4 * s2], accxB[m]);
+                        }
                     }
                 }
             }
+        }
+        if constexpr (T4) {
+#pragma unroll
+            for (int i = 0; i < NOWN; i++) {
+                accA[MT - 1][i] += tail_finish(tqA[i]);
+                accB[MT - 1][i] += tail_finish(tqB[i]);
+            }
+            if constexpr (XMODE == 2) { accxA[0] = tail_finish(accxA[0]); accxB[0] = tail_finish(accxB[0]); }
         }
     }
 
@@ -700,15 +793,16 @@ struct Blk {
             if (split_mode(NT)) {
 #pragma unroll
                 for (int m = 0; m < MXS; m++) { accxA[m] = f32x4{0.f, 0.f, 0.f, 0.f}; accxB[m] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                if (wave >= 4) fwd_loop2<1, true, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, NT - 1, share_lo(wave - 4));
-                else fwd_loop2<2, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+                if (T4 && wave == 7) fwd_loop2<1, T4 ? 2 : 1, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, NT - 1, share_lo(3));
+                else if (wave >= 4) fwd_loop2<1, 1, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, NT - 1, share_lo(wave - 4));
+                else fwd_loop2<2, 0, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
                 collect_split<false>(accA, accxA);
                 __syncthreads();                 // wave 4 has taken the first set out of the hand-off buffer
                 collect_split<false>(accB, accxB);
-            } else if (nown >= 2) fwd_loop2<2, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
-            else if (nown == 1) fwd_loop2<1, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+            } else if (nown >= 2) fwd_loop2<2, 0, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+            else if (nown == 1) fwd_loop2<1, 0, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
         } else {
-            if (nown >= 1) fwd_loop2<1, false, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
+            if (nown >= 1) fwd_loop2<1, 0, STREAM>(accA, accB, WA, WB, NT, KB, tail8, accxA, accxB, 0, 0);
         }
     }
 
@@ -920,29 +1014,36 @@ struct Blk {
     // BIT < 0: the mask bytes are 0/1 as stored (single plane written with BIT 0 + OVERWRITE); BIT >= 0 selects a plane.
     // Same structure as fwd_loop: tiles owned is a template parameter, two register sets, no masks.
     // ---------------------------------------------------------------------------------------
-    // XTRA: besides its NOWN full output tiles the wave computes batch tiles [xm0, ..) of the split output tile xt
-    template <int NS, int NOWN, int BIT, bool TRICK, bool XTRA>
+    // XMODE (see share_lo): besides its NOWN output tiles the wave computes its share of the split output tile xt
+    template <int NS, int NOWN, int BIT, bool TRICK, int XMODE>
     __device__ __forceinline__ void bwd_loop(f32x4 (&acc)[MT][NTW], const float* W, int NTk, const lds_f32* seed,
                                              const lds_f32* wvec, bool tail8, int NTblk, f32x4 (&accx)[MXS], int xt, int xm0) {
+        constexpr bool XTRA = XMODE != 0;
+        constexpr int NX = XMODE == 2 ? 1 : MXS;
         const float* wp = W + (((size_t)tile0() * NTblk) << 8) + (lane << 2);
         const size_t tst = ((size_t)tstep() * NTblk) << 8;
-        const lds_u8* mp = L.mask + c * MSTRIDE + 4 * g;
+        // batch row whose mask / seed this lane feeds as the A operand of batch tile mt (T4: the tail's rows c & 3)
+        auto brow = [&](int mt) { return (T4 && mt == MT - 1) ? TROW + (c & 3) : 16 * mt + c; };
+        const lds_u8* mp = L.mask + 4 * g;
         const lds_f32* wvp = wvec + 4 * g;
         float sd[MT][NS];
         if (!TRICK) {
 #pragma unroll
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-                for (int j = 0; j < NS; j++) sd[mt][j] = seed[(16 * mt + c) * NS + j];
+                for (int j = 0; j < NS; j++) sd[mt][j] = seed[brow(mt) * NS + j];
         }
+        f32x4 tq[NOWN];                                             // T4: the tail tile's 4x4x1 accumulators
+#pragma unroll
+        for (int i = 0; i < NOWN; i++) tq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         // the split tile's share: its weight rows, and the mask / seed rows of its batch tiles (a run-time range)
         const float* wpx = W + (((size_t)xt * NTblk) << 8) + (lane << 2);
-        int xrow[MXS];
-        float sdx[MXS][NS];
+        int xrow[NX];
+        float sdx[NX][NS];
         if (XTRA) {
 #pragma unroll
-            for (int m = 0; m < MXS; m++) {
-                xrow[m] = 16 * (xm0 + m < MT ? xm0 + m : xm0) + c;
+            for (int m = 0; m < NX; m++) {
+                xrow[m] = XMODE == 2 ? TROW + (c & 3) : 16 * (xm0 + m < MT ? xm0 + m : xm0) + c;
 #pragma unroll
                 for (int j = 0; j < NS; j++) sdx[m][j] = seed[xrow[m] * NS + j];
             }
@@ -958,7 +1059,7 @@ struct Blk {
         unsigned mwn[MT];
         auto load_masks = [&](int ch) {
 #pragma unroll
-            for (int mt = 0; mt < MT; mt++) mwn[mt] = *reinterpret_cast<const lds_u32*>(mp + 16 * mt * MSTRIDE + 16 * ch);
+            for (int mt = 0; mt < MT; mt++) mwn[mt] = *reinterpret_cast<const lds_u32*>(mp + brow(mt) * MSTRIDE + 16 * ch);
         };
         auto mac = [&](const f32x4 (&bin)[NOWN], const f32x4& binx, int ch) {
             f32x4 wv[NS], b[NOWN], bx;
@@ -973,7 +1074,7 @@ struct Blk {
 #ifdef RLC_BWD_PREFETCH
                 unsigned mw = mwn[mt];
 #else
-                unsigned mw = *reinterpret_cast<const lds_u32*>(mp + 16 * mt * MSTRIDE + 16 * ch);
+                unsigned mw = *reinterpret_cast<const lds_u32*>(mp + brow(mt) * MSTRIDE + 16 * ch);
 #endif
                 if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x01010101u;
                 float mf[4];
@@ -999,10 +1100,13 @@ struct Blk {
 #pragma unroll
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s], b[i][s], acc[mt][i]);
+                    for (int mt = 0; mt < MT; mt++) {
+                        if (T4 && mt == MT - 1) tq[i] = mfma4(av[mt][s], b[i][s], tq[i]);
+                        else acc[mt][i] = mfma16(av[mt][s], b[i][s], acc[mt][i]);
+                    }
             if (XTRA) {
 #pragma unroll
-                for (int m = 0; m < MXS; m++) {
+                for (int m = 0; m < NX; m++) {
                     unsigned mw = *reinterpret_cast<const lds_u32*>(L.mask + xrow[m] * MSTRIDE + 4 * g + 16 * ch);
                     if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x01010101u;
                     float mf[4];
@@ -1016,7 +1120,7 @@ struct Blk {
                             for (int j = 0; j < NS; j++) v += sdx[m][j] * wv[j][s];
                             f *= v;
                         }
-                        accx[m] = mfma16(f, bx[s], accx[m]);
+                        accx[m] = XMODE == 2 ? mfma4(f, bx[s], accx[m]) : mfma16(f, bx[s], accx[m]);
                     }
                 }
             }
@@ -1030,7 +1134,7 @@ struct Blk {
         // its mask dword read ahead of the 4*NOWN MFMAs that consume the previous one
         auto pin = [&]() {
             __builtin_amdgcn_sched_group_barrier(0x020, NOWN + (XTRA ? 1 : 0), 0);              // VMEM read
-            __builtin_amdgcn_sched_group_barrier(0x100, NS + MT + (XTRA ? MXS : 0), 0);         // DS read: wvec rows + every mask dword
+            __builtin_amdgcn_sched_group_barrier(0x100, NS + MT + (XTRA ? NX : 0), 0);          // DS read: wvec rows + every mask dword
         };
         for (; ch + 2 <= NTk; ch += 2) {
             loadB(b1, bx1, ch + 1);
@@ -1059,7 +1163,7 @@ struct Blk {
             f32x2 av[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
-                unsigned mw = *reinterpret_cast<const RLC_LDS unsigned short*>(L.mask + (16 * mt + c) * MSTRIDE + 16 * NTk + 2 * g);
+                unsigned mw = *reinterpret_cast<const RLC_LDS unsigned short*>(L.mask + brow(mt) * MSTRIDE + 16 * NTk + 2 * g);
                 if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x0101u;
                 float mf[4];
                 mask4(mw, mf, std::integral_constant<int, BIT>{});
@@ -1081,12 +1185,15 @@ struct Blk {
 #pragma unroll
                 for (int i = 0; i < NOWN; i++)
 #pragma unroll
-                    for (int mt = 0; mt < MT; mt++) acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+                    for (int mt = 0; mt < MT; mt++) {
+                        if (T4 && mt == MT - 1) tq[i] = mfma4(av[mt][s2], bt[i][s2], tq[i]);
+                        else acc[mt][i] = mfma16(av[mt][s2], bt[i][s2], acc[mt][i]);
+                    }
             if (XTRA) {
                 f32x2 btx = *reinterpret_cast<const f32x2*>(W + (((size_t)xt * NTblk + NTk) << 8) + tofs);
                 if (TRICK) btx = btx * wv[0];
 #pragma unroll
-                for (int m = 0; m < MXS; m++) {
+                for (int m = 0; m < NX; m++) {
                     unsigned mw = *reinterpret_cast<const RLC_LDS unsigned short*>(L.mask + xrow[m] * MSTRIDE + 16 * NTk + 2 * g);
                     if (BIT >= 0) mw = (mw >> (BIT >= 0 ? BIT : 0)) & 0x0101u;
                     float mf[4];
@@ -1100,10 +1207,15 @@ struct Blk {
                             for (int j = 0; j < NS; j++) v += sdx[m][j] * wv[j][s2];
                             f *= v;
                         }
-                        accx[m] = mfma16(f, btx[s2], accx[m]);
+                        accx[m] = XMODE == 2 ? mfma4(f, btx[s2], accx[m]) : mfma16(f, btx[s2], accx[m]);
                     }
                 }
             }
+        }
+        if constexpr (T4) {
+#pragma unroll
+            for (int i = 0; i < NOWN; i++) acc[MT - 1][i] += tail_finish(tq[i]);
+            if constexpr (XMODE == 2) accx[0] = tail_finish(accx[0]);
         }
         if (TRICK) {
 #pragma unroll
@@ -1114,8 +1226,9 @@ struct Blk {
             }
             if (XTRA) {
 #pragma unroll
-                for (int m = 0; m < MXS; m++)
-                    accx[m] = accx[m] * *reinterpret_cast<const lds_f32x4*>(&seed[16 * (xm0 + m < MT ? xm0 + m : xm0) + 4 * g]);
+                for (int m = 0; m < NX; m++)
+                    accx[m] = accx[m] * *reinterpret_cast<const lds_f32x4*>(
+                                            &seed[(XMODE == 2 ? TROW : 16 * (xm0 + m < MT ? xm0 + m : xm0)) + 4 * g]);
             }
         }
     }
@@ -1146,13 +1259,14 @@ struct Blk {
             if (split_mode(NT)) {                  // workgroup-uniform
 #pragma unroll
                 for (int m = 0; m < MXS; m++) accx[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (wave >= 4) bwd_loop<NS, 1, BIT, TRICK, true>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, NT - 1, share_lo(wave - 4));
-                else bwd_loop<NS, 2, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
+                if (T4 && wave == 7) bwd_loop<NS, 1, BIT, TRICK, T4 ? 2 : 1>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, NT - 1, share_lo(3));
+                else if (wave >= 4) bwd_loop<NS, 1, BIT, TRICK, 1>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, NT - 1, share_lo(wave - 4));
+                else bwd_loop<NS, 2, BIT, TRICK, 0>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
                 collect_split<ACCUM>(acc, accx);
-            } else if (nown >= 2) bwd_loop<NS, 2, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
-            else if (nown == 1) bwd_loop<NS, 1, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
+            } else if (nown >= 2) bwd_loop<NS, 2, BIT, TRICK, 0>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
+            else if (nown == 1) bwd_loop<NS, 1, BIT, TRICK, 0>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
         } else {
-            if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK, false>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
+            if (nown >= 1) bwd_loop<NS, 1, BIT, TRICK, 0>(acc, W, NTk, seed, wvec, tail8, NTblk, accx, 0, 0);
         }
 #ifdef RLC_STAMPS
         if (lane == 0 && stamp_buf) stamp_buf[56 + wave] += (float)(clock64() - t_w0);   // per-wave k-loop cycles

@@ -6,10 +6,17 @@
 #error "compile with -DRLC_MT=<M tiles> -DRLC_NTW=<N tiles per wave> -DRLC_AD=<action dim>"
 #endif
 
+#ifndef RLC_T4
+#define RLC_T4 0            // 1: the tail-of-four variant (mfma_blocks.h, Blk's T4), entry point rlc_naf_mfma_launch_t4_<MT>_<NTW>_<AD>
+#endif
+#if RLC_T4
+#define RLC_CAT_(a, b, c) rlc_naf_mfma_launch_t4_##a##_##b##_##c
+#else
 #define RLC_CAT_(a, b, c) rlc_naf_mfma_launch_##a##_##b##_##c
+#endif
 #define RLC_CAT(a, b, c) RLC_CAT_(a, b, c)
 
 int RLC_CAT(RLC_MT, RLC_NTW, RLC_AD)(const RlcNafDev& dv, int first_agent, int n_agents, int n_updates, int source,
                                      const long long* idx_dev, int grad_taps, hipStream_t st, const RlcNafRollout* rollout) {
-    return naf_launch_t<RLC_MT, RLC_NTW, RLC_AD>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout);
+    return naf_launch_t<RLC_MT, RLC_NTW, RLC_AD, RLC_T4 != 0>(dv, first_agent, n_agents, n_updates, source, idx_dev, grad_taps, st, rollout);
 }

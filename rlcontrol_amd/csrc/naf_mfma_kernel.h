@@ -87,7 +87,8 @@ __device__ __forceinline__ void naf_head_ref(const RlcNafDims& d, int j, int& ow
     ow = d.Wn[c] + jj; stride = d.A - 1 - c; ob = d.bn[c] + jj;
 }
 
-template <int MT, int NTW, int AD>
+// T4: the minibatch ends within the first four rows of its last tile (mfma_blocks.h, Blk's T4; the launcher checks it)
+template <int MT, int NTW, int AD, bool T4>
 __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev dv, int first_agent, int n_updates,
                                                                        int source, const long long* host_idx,
                                                                        int grad_taps, const RlcNafRollout* rollout) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
     constexpr int MSTRIDE = mask_stride(8 * NTW);
     constexpr int NN = AD * (AD - 1) / 2, NH = AD + NN;
     static_assert(NH <= NHP, "head count");
-    using U = Blk<MT, NTW, MSTRIDE, false>;
+    using U = Blk<MT, NTW, MSTRIDE, false, false, T4>;
     constexpr int MB = U::MB;
     const RlcNafDims d = dv.d;
     U u;
@@ -415,13 +416,14 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
     }
 }
 
-template <int MT, int NTW, int AD>
+template <int MT, int NTW, int AD, bool T4>
 int naf_launch_t(const RlcNafDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
                  int grad_taps, hipStream_t st, const RlcNafRollout* rollout) {
     constexpr int MSTRIDE = mask_stride(8 * NTW);
     const size_t lds = nsmem_carve<MSTRIDE>(dv.d, MT, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "MFMA NAF kernel needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = rlc_naf_update_mfma_kernel<MT, NTW, AD>;
+    RLC_REQUIRE(!T4 || rlc_tail4(dv.d.B, MT), "tail-of-four kernel launched for batch %d", dv.d.B);
+    auto kern = rlc_naf_update_mfma_kernel<MT, NTW, AD, T4>;
     static bool attr_set = false;
     if (!attr_set) {
         RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

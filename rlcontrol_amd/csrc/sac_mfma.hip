@@ -14,6 +14,16 @@
     int rlc_sac_mfma_launch_##M##_##N_##_##A_(const RlcSacDev&, int, int, int, int, const long long*, const float*, int, \
                                               hipStream_t, const RlcSacRollout*);
 RLC_FOR_SAC(RLC_DECL3)
+// tail-of-four variants (compiled for the seven-tile shapes only: batch 97..100)
+#ifdef RLC_ONLY_7_1
+#define RLC_FOR_SAC_T4(X) X(7, 1, 1)
+#else
+#define RLC_FOR_SAC_T4(X) X(7, 1, 1) X(7, 2, 1) X(7, 1, 2) X(7, 2, 2)
+#endif
+#define RLC_DECLT4(M, N_, A_)                                                                                          \
+    int rlc_sac_mfma_launch_t4_##M##_##N_##_##A_(const RlcSacDev&, int, int, int, int, const long long*, const float*, int, \
+                                                 hipStream_t, const RlcSacRollout*);
+RLC_FOR_SAC_T4(RLC_DECLT4)
 
 static inline int sac_mt_for(int B) { return B <= 32 ? 2 : (B <= 64 ? 4 : (B <= 112 ? 7 : 8)); }
 static inline int sac_ntw_for(const RlcSacDims& d) {
@@ -42,6 +52,12 @@ int rlc_launch_sac_update_mfma(const RlcSacDev& dv, int first_agent, int n_agent
     RLC_REQUIRE(dv.d.blocked, "the MFMA kernel reads tile-blocked weights (rlc_sac_set_kernel re-packs them)");
     RLC_REQUIRE(!(rollout && eps_dev), "the on-device loop draws its own eps");
     const int mt = sac_mt_for(dv.d.B), ntw = sac_ntw_for(dv.d);
+#define RLC_CASET4(M, N_, A_)                                                  \
+    if (mt == M && ntw == N_ && dv.d.A == A_ && rlc_tail4_enabled(dv.d.B, M))  \
+        return rlc_sac_mfma_launch_t4_##M##_##N_##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, eps_dev, \
+                                                        grad_taps, st, rollout);
+    RLC_FOR_SAC_T4(RLC_CASET4)
+#undef RLC_CASET4
 #define RLC_CASE3(M, N_, A_)                       \
     if (mt == M && ntw == N_ && dv.d.A == A_)      \
         return rlc_sac_mfma_launch_##M##_##N_##_##A_(dv, first_agent, n_agents, n_updates, source, idx_dev, eps_dev, \

@@ -116,7 +116,8 @@ __device__ inline void sac_blk_sum2(float a, float b, lds_f32* red, float& sa, f
     lds_barrier();
 }
 
-template <int MT, int NTW, int AD>
+// T4: the minibatch ends within the first four rows of its last tile (mfma_blocks.h, Blk's T4; the launcher checks it)
+template <int MT, int NTW, int AD, bool T4>
 __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev dv, int first_agent, int n_updates,
                                                                        int source, const long long* host_idx,
                                                                        const float* eps_in, int grad_taps,
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int MSTRIDE = mask_stride(8 * NTW);
     constexpr int NS = 2 * AD;
-    using U = Blk<MT, NTW, MSTRIDE, true>;
+    using U = Blk<MT, NTW, MSTRIDE, true, false, T4>;
     constexpr int MB = U::MB;
     const RlcSacDims d = dv.d;
     U u;
@@ -560,13 +561,14 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
     }
 }
 
-template <int MT, int NTW, int AD>
+template <int MT, int NTW, int AD, bool T4>
 int sac_launch_t(const RlcSacDev& dv, int first_agent, int n_agents, int n_updates, int source, const long long* idx_dev,
                  const float* eps_dev, int grad_taps, hipStream_t st, const RlcSacRollout* rollout) {
     constexpr int MSTRIDE = mask_stride(8 * NTW);
     const size_t lds = ssmem_carve<MSTRIDE>(dv.d, MT, nullptr, nullptr);
     RLC_REQUIRE(lds <= 160 * 1024, "MFMA SAC kernel needs %zu B of LDS (> 160 KiB)", lds);
-    auto kern = rlc_sac_update_mfma_kernel<MT, NTW, AD>;
+    RLC_REQUIRE(!T4 || rlc_tail4(dv.d.B, MT), "tail-of-four kernel launched for batch %d", dv.d.B);
+    auto kern = rlc_sac_update_mfma_kernel<MT, NTW, AD, T4>;
     static bool attr_set = false;
     if (!attr_set) {
         RLC_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -56,7 +56,10 @@ def _batch(rng, B, S, A):
 
 KERNELS = ["generic", "mfma"]
 CASES = [((3, 1, 200, 200, 200), 100), ((3, 1, 200, 200, 200), 32), ((8, 2, 200, 200, 200), 64),
-         ((8, 2, 64, 48, 40), 17), ((1, 1, 16, 16, 16), 5), ((3, 1, 128, 128, 128), 128)]
+         ((8, 2, 64, 48, 40), 17), ((1, 1, 16, 16, 16), 5), ((3, 1, 128, 128, 128), 128),
+         # batches that end inside the first four rows of the seventh tile run the tail-of-four kernels (mfma_blocks.h T4;
+         # 100 above is the full tail): a one-row and a three-row tail, and 101 = the first batch that must not take them
+         ((3, 1, 200, 200, 200), 97), ((8, 2, 200, 160, 144), 99), ((8, 2, 200, 160, 144), 101)]
 
 
 def _skip_unless_supported(pop, kernel):
