@@ -78,8 +78,10 @@ def _pop(dims, B, n_agents=1, cap=2048, lr=1e-3, kernel="auto"):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("dims,B", CASES + [((8, 1, 128, 96), 100), ((4, 2, 256, 144), 48),
-                                            ((4, 2, 256, 144), 97), ((8, 2, 200, 200), 101)])   # tail-of-four edge cases
+                                            ((8, 2, 200, 200), 97), ((8, 2, 200, 200), 101)])   # tail-of-four edge cases
 def test_naf_hip_update_matches_oracle(hip_lib, dims, B, kernel):
+    if B in (97, 101) and kernel != "mfma":
+        pytest.skip("tail-of-four edge cases concern the MFMA kernel only")
     d = NafDims(*dims)
     th = init_params(d, 2)
     smin, smax, amax = _bounds(dims[0], dims[1])

@@ -92,6 +92,8 @@ def _pop(dims, B, n_agents=1, alpha=0.5, cap=2048, kernel="auto"):
 @pytest.mark.parametrize("dims,B", CASES + [((3, 2, 128, 96, 112, 128), 100), ((8, 1, 200, 160, 144, 176), 64),
                                             ((8, 1, 200, 160, 144, 176), 98), ((3, 1, 128, 128, 128, 128), 101)])   # tail-of-four edge cases
 def test_sac_hip_update_matches_oracle(hip_lib, dims, B, kernel):
+    if B in (98, 101) and kernel != "mfma":
+        pytest.skip("tail-of-four edge cases concern the MFMA kernel only")
     d = SacDims(*dims)
     th = _benign(d, init_params(d, 1))
     pop = _pop(dims, B, kernel=kernel)
