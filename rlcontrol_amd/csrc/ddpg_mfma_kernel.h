@@ -333,6 +333,7 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
         u.template wgrad_adam_pre<1, AD, -1, false, false, NPRE>(L.dq, L.a, HC, th + d.oWc2, m_c + d.oWc2, v_c + d.oWc2, alpha_c,
                      tap_gc ? tap_gc + d.oWc2 : nullptr, tt + d.oWc2, tau, L.wvec, pre);
         // small critic tensors: Wc3, bc2 (column owners), bc3 (one thread)
+        u.sub_begin();
         {
             const int NT = (HC + 15) >> 4;
 #pragma unroll
@@ -366,7 +367,9 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                 }
             }
         }
+        u.sub_stamp(29);              // (diagnostic build) the small tensors; 30: wave 0 waiting for the slowest wave
         __syncthreads();
+        u.sub_stamp(30);
         STAMP();
         if (tid == 0) { pw[2] *= 0.9f; pw[3] *= 0.999f; }
 

@@ -1444,6 +1444,9 @@ struct Blk {
                                                    float alpha, float* tapp, float* Wt, float tau, const lds_f32* wvec,
                                                    WgPre2& pre) {
         if constexpr (ablate(0)) return;
+#ifdef RLC_STAMPS
+        const long long t_wg0 = clock64();
+#endif
         const int NT = (N + 15) >> 4;
         const int NMT = (H1 + 15) >> 4;                  // MFMA rows: the hbuf units; extra rows below
         const int nch = (NMT + 3) >> 2, cbase = NMT / nch, crem = NMT % nch;    // chunk sizes differ by at most one
@@ -1477,7 +1480,7 @@ struct Blk {
                 kq[q] = (EXACT || q < nq ? 16 * (m0 + q) : 0) + c;    // rows past the chunk alias tile 0 (never stored)
             }
             const lds_u8* mrow = L.mask + 16 * t + c;
-            sub_begin();
+            sub_stamp(28);               // (diagnostic build) since the last item's epilogue: next prefetch issued, item geometry
             // The batch is walked in MT groups of 4 k-steps (rows 16 gi + 4 j + gperm), fully unrolled, the operands
             // of the next group in flight while the current group's 4*MCC MFMAs issue.  LDC: compile-time leading
             // dimension of hbuf (every LDS address is then base + immediate), 0 = runtime.
@@ -1488,6 +1491,11 @@ struct Blk {
                 const lds_f32* hq[MCC];
 #pragma unroll
                 for (int q = 0; q < MCC; q++) hq[q] = EXACT ? L.hbuf + gperm * ld + kq[0] + 16 * q : L.hbuf + gperm * ld + kq[q];
+                // a second set of bases 64 rows down: with a compile-time leading dimension every activation read is
+                // then base + a 16-bit immediate (row * ld * 4 bytes passes 64 KB at row 82 of 112)
+                const lds_f32* hq2[MCC];
+#pragma unroll
+                for (int q = 0; q < MCC; q++) hq2[q] = hq[q] + 64 * ld;
                 const lds_f32* sp = seed + gperm * NS;
                 const lds_u8* mp = mrow + gperm * MSTRIDE;
                 auto load_ops = [&](Ops& o, int gi) {
@@ -1498,7 +1506,7 @@ struct Blk {
                         for (int jj = 0; jj < NS; jj++) o.sd[j][jj] = sp[row * NS + jj];
                         o.mk[j] = mp[row * MSTRIDE];
 #pragma unroll
-                        for (int q = 0; q < MCC; q++) o.hf[j][q] = hq[q][row * ld];
+                        for (int q = 0; q < MCC; q++) o.hf[j][q] = (LDC && row >= 64) ? hq2[q][(row - 64) * ld] : hq[q][row * ld];
                     }
                 };
                 auto mac_ops = [&](const Ops& o, int gi) {
@@ -1530,6 +1538,19 @@ struct Blk {
             else kloop(std::integral_constant<int, 0>{});
             sub_stamp(22);
             const bool n4ok = 16 * t + 4 * g < N;
+            // Every prefetched register of the item is demanded HERE, before the first store of the epilogue.  gfx9's
+            // vmcnt counts stores as well as loads, in issue order, and hipcc derives each tile's wait from the loads
+            // alone (vmcnt(13), (9), (5), (1) for tiles 0..3): with the previous tiles' stores in the queue behind them
+            // the later tiles' waits then stand for "my own stores of a moment ago have been written back" -- a store
+            // round trip inside every item.  One wait up front covers only loads issued a k-loop ago.  (All four sets: a
+            // three-tile item's fourth was loaded as well, wg_issue.)
+            if constexpr (!GONLY && !ablate(1)) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if constexpr (NOPOL) asm volatile("" ::"v"(P.w[q]), "v"(P.m[q]), "v"(P.v[q]));
+                    else asm volatile("" ::"v"(P.w[q]), "v"(P.m[q]), "v"(P.v[q]), "v"(P.t[q]));
+                }
+            }
             if constexpr (ablate(1)) {       // keep the accumulators live, store nothing
 #pragma unroll
                 for (int q = 0; q < MCC; q++)
@@ -1656,6 +1677,9 @@ struct Blk {
             }
         }
         sub_stamp(24);
+#ifdef RLC_STAMPS
+        if (lane == 0 && stamp_buf) stamp_buf[32 + wave] += (float)(clock64() - t_wg0);   // per-wave time in this call
+#endif
     }
 
     // the same through this block's Adam form (TADAM: torch's step)

@@ -56,6 +56,9 @@ def main():
     print("  thread 0 inside sample+gather: ring/counter loads %.0f, sampler %.0f, gather %.0f" % tuple(sg))
     sub = pop.last_tap(0, "grads_c")[21:25] / U
     print("  wave-0 inside both wgrad GEMMs: prefetch-issue %.0f, k-loop %.0f, epilogue(+next prefetch wait) %.0f, action rows %.0f" % tuple(sub))
+    g = pop.last_tap(0, "grads_c") / U
+    print("  wave-0 between items (next prefetch issue + geometry) %.0f; critic phase: small tensors %.0f, barrier wait %.0f" % (g[28], g[29], g[30]))
+    print("  per-wave cycles inside both wgrad calls: " + " ".join("%.0f" % v for v in g[32:40]))
 
 
 if __name__ == "__main__":
