@@ -207,6 +207,10 @@ int rlc_sac_init_target(rlc_sac* h, int32_t agent);                       /* sac
  * eps: [n][A] N(0,1) draws standing in for tf.random_normal (:286), or NULL -> device Philox. */
 int rlc_sac_act(rlc_sac* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
                 float* out_actions);
+/* the same forward queued behind the update just launched / fetched by step() -- see rlc_ddpg_act_queue
+ * (agents/base_agent.py:54-63, experiment.py:132-135).  eps is read at queue time. */
+int rlc_sac_act_queue(rlc_sac* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps);
+int rlc_sac_act_fetch(rlc_sac* h, int32_t first_agent, int32_t n, float* out_actions);
 /* BaseAgent.learn for every agent: sample_batch + update_network + update_target_network
  * (agents/SoftActorCritic.py:113-126).  host_indices as in rlc_ddpg_update; eps [n_agents][n_updates][batch][A] or NULL. */
 int rlc_sac_update(rlc_sac* h, int32_t n_updates, const int64_t* host_indices, const float* eps);
@@ -279,6 +283,9 @@ int rlc_kl_init_target(rlc_kl* h, int32_t agent);              /* reversekl_netw
  * eps: [n][A] N(0,1) draws standing in for normal.sample(), or NULL -> device Philox. */
 int rlc_kl_act(rlc_kl* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
                float* out_actions);
+/* queued / fetched as rlc_ddpg_act_queue / rlc_ddpg_act_fetch */
+int rlc_kl_act_queue(rlc_kl* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps);
+int rlc_kl_act_fetch(rlc_kl* h, int32_t first_agent, int32_t n, float* out_actions);
 /* BaseAgent.learn for every agent: sample_batch + update_network + update_target_network.
  * host_indices as in rlc_ddpg_update; eps [n_agents][n_updates][batch][A] or NULL. */
 int rlc_kl_update(rlc_kl* h, int32_t n_updates, const int64_t* host_indices, const float* eps);
@@ -335,6 +342,9 @@ int rlc_naf_init_target(rlc_naf* h, int32_t agent);                       /* naf
  * fetch of sample_action (:157-158), column c = {exp(clip(diag_c)), below-diagonal entries}: the caller forms
  * noise_scale * pinv(L L^T) and samples on the host exactly as the reference does (:161-174). */
 int rlc_naf_act(rlc_naf* h, int32_t first_agent, int32_t n, const double* states, float* out_mu, float* out_lcols);
+/* queued / fetched as rlc_ddpg_act_queue / rlc_ddpg_act_fetch (the host draws the exploration sample after the fetch) */
+int rlc_naf_act_queue(rlc_naf* h, int32_t first_agent, int32_t n, const double* states);
+int rlc_naf_act_fetch(rlc_naf* h, int32_t first_agent, int32_t n, float* out_mu, float* out_lcols);
 /* BaseAgent.learn for every agent: sample_batch + NAF_Network_Manager.update_network (agents/NAF.py:69-75) */
 int rlc_naf_update(rlc_naf* h, int32_t n_updates, const int64_t* host_indices);
 int rlc_naf_update_batch(rlc_naf* h, int32_t agent, int32_t batch, const double* states, const double* actions,

@@ -26,13 +26,13 @@ EXPORTS = (
     "rlc_ddpg_last_tap", "rlc_ddpg_enable_grad_taps", "rlc_debug_fail_next_split",
     "rlc_timer_begin", "rlc_timer_end",
     "rlc_sac_create", "rlc_sac_param_count", "rlc_sac_set_blob", "rlc_sac_get_blob", "rlc_sac_set_beta_powers",
-    "rlc_sac_get_beta_powers", "rlc_sac_init_target", "rlc_sac_act", "rlc_sac_update", "rlc_sac_update_batch",
+    "rlc_sac_get_beta_powers", "rlc_sac_init_target", "rlc_sac_act", "rlc_sac_act_queue", "rlc_sac_act_fetch", "rlc_sac_update", "rlc_sac_update_batch",
     "rlc_sac_last_tap", "rlc_sac_enable_grad_taps", "rlc_sac_set_kernel", "rlc_sac_get_kernel",
     "rlc_kl_create", "rlc_kl_param_count", "rlc_kl_set_blob", "rlc_kl_get_blob", "rlc_kl_set_step", "rlc_kl_get_step",
-    "rlc_kl_init_target", "rlc_kl_act", "rlc_kl_update", "rlc_kl_update_batch", "rlc_kl_last_tap",
+    "rlc_kl_init_target", "rlc_kl_act", "rlc_kl_act_queue", "rlc_kl_act_fetch", "rlc_kl_update", "rlc_kl_update_batch", "rlc_kl_last_tap",
     "rlc_kl_enable_grad_taps", "rlc_kl_set_kernel", "rlc_kl_get_kernel", "rlc_kl_set_split",
     "rlc_naf_create", "rlc_naf_param_count", "rlc_naf_set_blob", "rlc_naf_get_blob", "rlc_naf_get_beta_powers",
-    "rlc_naf_init_target", "rlc_naf_act", "rlc_naf_update", "rlc_naf_update_batch", "rlc_naf_last_tap",
+    "rlc_naf_init_target", "rlc_naf_act", "rlc_naf_act_queue", "rlc_naf_act_fetch", "rlc_naf_update", "rlc_naf_update_batch", "rlc_naf_last_tap",
     "rlc_naf_enable_grad_taps", "rlc_naf_set_kernel", "rlc_naf_get_kernel",
     "rlc_ddpg_rollout_create", "rlc_ddpg_rollout_run", "rlc_sac_rollout_create", "rlc_sac_rollout_run", "rlc_kl_rollout_create", "rlc_kl_rollout_run",
     "rlc_naf_rollout_create", "rlc_naf_rollout_run", "rlc_rollout_counts", "rlc_rollout_train_log",

@@ -14,6 +14,9 @@ from ..hip_naf import NAFPopulation, init_params
 
 
 class NAF_Network_Manager(BaseNetwork_Manager):
+    queues_next_action = True        # update_from_replay(indices, next_state=...) queues the forward step() will fetch
+    _queued_state = None
+
     def __init__(self, config):
         super(NAF_Network_Manager, self).__init__(config)
         check_norm_type(config, "NAF", ('none', 'input_norm', 'layer'))
@@ -49,20 +52,33 @@ class NAF_Network_Manager(BaseNetwork_Manager):
             if is_start:
                 self.train_ep_count += 1
             self.train_global_steps += 1
-            mu, lc = self.population.act(state.reshape(-1, self.state_dim), with_lcols=True)
+            queued, self._queued_state = self._queued_state, None
+            if queued is not None and np.array_equal(queued, np.asarray(state, np.float64).reshape(-1)):
+                mu, lc = self.population.act_fetch(1)        # queued behind the last update (update_from_replay)
+            else:
+                mu, lc = self.population.act(state.reshape(-1, self.state_dim), with_lcols=True)
             if self.use_external_exploration:
                 return self.exploration_policy.generate(mu, self.train_global_steps)
             return self._sample_action(mu[0].astype(np.float64), lc[0].astype(np.float64))
+        self._queued_state = None
         if is_start:
             self.eval_ep_count += 1
         self.eval_global_steps += 1
         return self.population.act(state.reshape(-1, self.state_dim)).reshape(-1)
 
     def update_network(self, state, action, next_state, reward, gamma):
+        self._queued_state = None
         self.population.update_batch(0, state, action, next_state, reward, gamma)
 
-    def update_from_replay(self, logical_indices):
+    def update_from_replay(self, logical_indices, next_state=None):
+        """`next_state`: the observation Experiment asks an action for next (experiment.py:132-135): its greedy forward
+        (mu and the L columns) is queued behind the update -- one launch sequence, one synchronisation per environment
+        step; the exploration sample is still drawn on the host after the fetch, as the reference does (agents/NAF.py)."""
+        self._queued_state = None
         self.population.update(1, host_indices=logical_indices)
+        if next_state is not None:
+            self.population.act_queue(np.asarray(next_state, np.float64).reshape(1, -1))
+            self._queued_state = np.array(next_state, np.float64).reshape(-1)
 
 
 class NAF(BaseAgent):

@@ -54,6 +54,28 @@ class KL_Network_Manager(BaseNetwork_Manager):
     def _eps(self, n):
         return self.rng.standard_normal((n, self.action_dim)).astype(np.float32)
 
+    # ---- the training sample for the next state, queued behind the update (see agents/SoftActorCritic.py) ----
+    queues_next_action = True
+    _queued_state = None
+
+    def _queue_sample(self, next_state):
+        self._queued_rng = self.rng.get_state()
+        self.population.act_queue(np.expand_dims(next_state, 0), sample=True, eps=self._eps(1))
+        self._queued_state = np.array(next_state, np.float64)
+
+    def _drop_queued(self):
+        if self._queued_state is not None:
+            self.rng.set_state(self._queued_rng)
+            self._queued_state = None
+
+    def _train_sample(self, state):
+        queued, self._queued_state = self._queued_state, None
+        if queued is not None:
+            if np.array_equal(queued, np.asarray(state, np.float64)):
+                return self.population.act_fetch(1)[0]
+            self.rng.set_state(self._queued_rng)
+        return self.population.act(np.expand_dims(state, 0), sample=True, eps=self._eps(1))[0]
+
     def take_action(self, state, is_train, is_start):
         if is_train:
             if is_start:
@@ -61,7 +83,8 @@ class KL_Network_Manager(BaseNetwork_Manager):
             self.train_global_steps += 1
             if self.use_external_exploration:
                 raise NotImplementedError
-            return self.population.act(np.expand_dims(state, 0), sample=True, eps=self._eps(1))[0]
+            return self._train_sample(state)
+        self._drop_queued()
         if self.sample_for_eval:
             chosen = self.population.act(np.expand_dims(state, 0), sample=True, eps=self._eps(1))[0]
         else:
@@ -74,14 +97,18 @@ class KL_Network_Manager(BaseNetwork_Manager):
     def update_network(self, state_batch, action_batch, next_state_batch, reward_batch, gamma_batch):
         if self.use_true_q:
             raise NotImplementedError
+        self._drop_queued()
         n = len(np.reshape(reward_batch, -1))
         self.population.update_batch(0, state_batch, action_batch, next_state_batch, reward_batch, gamma_batch,
                                      eps=self._eps(n))
 
-    def update_from_replay(self, logical_indices):
+    def update_from_replay(self, logical_indices, next_state=None):
         if self.use_true_q:
             raise NotImplementedError
+        self._drop_queued()
         self.population.update(1, host_indices=logical_indices, eps=self._eps(len(logical_indices)))
+        if next_state is not None:
+            self._queue_sample(next_state)
 
 
 class ReverseKL_Network_Manager(KL_Network_Manager):

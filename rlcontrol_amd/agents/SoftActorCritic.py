@@ -15,6 +15,8 @@ from ..hip_sac import SACPopulation, init_params
 
 
 class SoftActorCritic_Network_Manager(BaseNetwork_Manager):
+    queues_next_action = True        # update_from_replay(indices, next_state=...) queues the forward step() will fetch
+
     def __init__(self, config):
         super(SoftActorCritic_Network_Manager, self).__init__(config)
         self.rng = np.random.RandomState(config.random_seed)
@@ -46,15 +48,41 @@ class SoftActorCritic_Network_Manager(BaseNetwork_Manager):
     def _eps(self, n):
         return self.rng.standard_normal((n, self.action_dim)).astype(np.float32)
 
+    # ---- the training sample for the next state, queued behind the update (one synchronisation per environment step) ----
+    _queued_state = None
+
+    def _queue_sample(self, next_state):
+        """Experiment asks step(next_state, is_train=True) next (experiment.py:132-135): that forward is queued now, with
+        the eps take_action would draw -- it is the next draw of the stream either way.  If something else is asked
+        first (an evaluation episode, another state), _drop_queued puts the stream back and the forward is discarded."""
+        self._queued_rng = self.rng.get_state()
+        self.population.act_queue(np.expand_dims(next_state, 0), sample=True, eps=self._eps(1))
+        self._queued_state = np.array(next_state, np.float64)
+
+    def _drop_queued(self):
+        if self._queued_state is not None:
+            self.rng.set_state(self._queued_rng)
+            self._queued_state = None
+
+    def _train_sample(self, state):
+        queued, self._queued_state = self._queued_state, None
+        if queued is not None:
+            if np.array_equal(queued, np.asarray(state, np.float64)):
+                return self.population.act_fetch(1)[0]
+            self.rng.set_state(self._queued_rng)
+        return self.population.act(np.expand_dims(state, 0), sample=True, eps=self._eps(1))[0]
+
     def take_action(self, state, is_train, is_start):
         if is_train:
             if is_start:
                 self.train_ep_count += 1
             self.train_global_steps += 1
             if self.use_external_exploration:
+                self._drop_queued()
                 greedy = self.population.act(np.expand_dims(state, 0), sample=False)[0]
                 return self.exploration_policy.generate(greedy, self.train_global_steps)
-            return self.population.act(np.expand_dims(state, 0), sample=True, eps=self._eps(1))[0]
+            return self._train_sample(state)
+        self._drop_queued()
         if is_start:
             self.eval_ep_count += 1
         self.eval_global_steps += 1
@@ -63,12 +91,16 @@ class SoftActorCritic_Network_Manager(BaseNetwork_Manager):
         return self.population.act(np.expand_dims(state, 0), sample=False)[0]
 
     def update_network(self, state_batch, action_batch, next_state_batch, reward_batch, gamma_batch):
+        self._drop_queued()
         n = len(np.reshape(reward_batch, -1))
         self.population.update_batch(0, state_batch, action_batch, next_state_batch, reward_batch, gamma_batch,
                                      eps=self._eps(n))
 
-    def update_from_replay(self, logical_indices):
+    def update_from_replay(self, logical_indices, next_state=None):
+        self._drop_queued()
         self.population.update(1, host_indices=logical_indices, eps=self._eps(len(logical_indices)))
+        if next_state is not None and not self.use_external_exploration:
+            self._queue_sample(next_state)
 
 
 class SoftActorCritic(BaseAgent):

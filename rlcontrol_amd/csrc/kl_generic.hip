@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_update_kernel(RlcSacDev dv_ar
 // predict_action (tanh(mean) * action_max) / sample_action (tanh(mean + std*eps) * action_max) for one state per
 // agent (reversekl_network.py:111-128): one workgroup per agent
 __global__ __launch_bounds__(kThreads) void rlc_kl_act_kernel(RlcSacDev dv, int first_agent, const float* states,
-                                                              const float* eps_in, int sample, float* out) {
+                                                              const float* eps_in, int sample, float* out,
+                                                              int* done_flag, int done_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcSacDims d = dv.d;
     const int S = d.S, A = d.A;
@@ -417,6 +418,13 @@ __global__ __launch_bounds__(kThreads) void rlc_kl_act_kernel(RlcSacDev dv, int 
     sac_policy_forward(d, th, L, dv.amax0, sample, 1);
     if (tid < A) out[(size_t)blockIdx.x * A + tid] = L.out[tid];
     if (sample && !eps_in && tid == 0) dv.noise_ctr[agent] += 1;
+    if (done_flag) {                                // (queued forward of a drop-in agent: one workgroup)
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();                     // the output stores first
+            __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 }  // namespace
@@ -445,10 +453,11 @@ int rlc_launch_kl_update(const RlcSacDev& dv, int first_agent, int n_agents, int
 }
 
 int rlc_launch_kl_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
-                      int sample, float* out_dev, hipStream_t st) {
+                      int sample, float* out_dev, hipStream_t st, int* done_flag, int done_val) {
     const size_t lds = sizeof(float) * sac_policy_lds_floats(dv.d);
+    RLC_REQUIRE(done_flag == nullptr || n == 1, "a completion flag needs a one-workgroup acting launch");
     hipLaunchKernelGGL(rlc_kl_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, eps_dev,
-                       sample, out_dev);
+                       sample, out_dev, done_flag, done_val);
     RLC_HIP(hipGetLastError());
     return 0;
 }

@@ -78,4 +78,4 @@ int rlc_launch_naf_update_mfma(const RlcNafDev& dv, int first_agent, int n_agent
 int rlc_launch_naf_eval(const RlcNafDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);
 // greedy action mu [n][A] and the L columns [n][A(A+1)/2] (column c = diag_c, then its below-diagonal entries)
 int rlc_launch_naf_act(const RlcNafDev& dv, int first_agent, int n, const float* states_dev, float* mu_dev,
-                       float* lcols_dev, hipStream_t st);
+                       float* lcols_dev, hipStream_t st, int* done_flag = nullptr, int done_val = 0);

@@ -294,8 +294,11 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_kernel(RlcNafDev dv_a
 }
 
 // greedy action + L columns for one state per agent (predict_action / sample_action's fetch, naf_network.py:144-158)
+// done_flag (or null): a word in host-visible memory that receives done_val once the launch's outputs are stored
+// (rlc_naf_act_queue; see rlc_ddpg_act_kernel)
 __global__ __launch_bounds__(kThreads) void rlc_naf_act_kernel(RlcNafDev dv, int first_agent, const float* states,
-                                                               float* mu_out, float* lcols_out) {
+                                                               float* mu_out, float* lcols_out, int* done_flag,
+                                                               int done_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcNafDims& d = dv.d;
     const int S = d.S, A = d.A, NL = A * (A + 1) / 2;
@@ -310,6 +313,13 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_act_kernel(RlcNafDev dv, int
         int p = 0;
         for (int c = 0; c < A; c++)
             for (int i = c; i < A; i++) lcols_out[(size_t)blockIdx.x * NL + p++] = naf_l_entry(d, L, i, c);
+    }
+    if (done_flag) {                                // (queued forward of a drop-in agent: one workgroup)
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();                     // the output stores first
+            __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -370,10 +380,11 @@ int rlc_launch_naf_update(const RlcNafDev& dv, int first_agent, int n_agents, in
 }
 
 int rlc_launch_naf_act(const RlcNafDev& dv, int first_agent, int n, const float* states_dev, float* mu_dev,
-                       float* lcols_dev, hipStream_t st) {
+                       float* lcols_dev, hipStream_t st, int* done_flag, int done_val) {
     const size_t lds = sizeof(float) * naf_policy_lds_floats(dv.d);
+    RLC_REQUIRE(done_flag == nullptr || n == 1, "a completion flag needs a one-workgroup acting launch");
     hipLaunchKernelGGL(rlc_naf_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, mu_dev,
-                       lcols_dev);
+                       lcols_dev, done_flag, done_val);
     RLC_HIP(hipGetLastError());
     return 0;
 }

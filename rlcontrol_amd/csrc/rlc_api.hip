@@ -100,6 +100,57 @@ int rlc_h_check_agent(const rlc_handle* h, int agent) { return check_agent(h, ag
 int rlc_h_use_device(const rlc_handle* h) { return use_device(h); }
 int rlc_h_ensure_io(rlc_handle* h, size_t bytes) { return ensure_io(h, bytes); }
 
+// ---- the queued acting forward of a drop-in agent (rlc_*_act_queue / rlc_*_act_fetch) ----------------------------
+// Zero-copy: the acting kernel reads its inputs from, and stores its outputs (and, for one agent, a completion word) into,
+// pinned host memory -- no copy operations on the stream, one kernel launch behind the update, one wait per step.
+// rlc_h_aq_begin: `floats` of pinned staging (inputs then outputs) are available in h->aq_host and no earlier queued forward
+// still uses them; flagged = the launch reports through the completion word (one-workgroup launches only).
+int rlc_h_aq_begin(rlc_handle* h, size_t floats, bool flagged) {
+    const size_t need = sizeof(float) * (floats + 4);
+    if (need > h->aq_cap) {
+        RLC_HIP(hipStreamSynchronize(h->st));
+        if (h->aq_host) RLC_HIP(hipHostFree(h->aq_host));
+        h->aq_host = nullptr; h->aq_cap = 0;
+        RLC_HIP(hipHostMalloc((void**)&h->aq_host, need * 2, hipHostMallocDefault));
+        h->aq_cap = need * 2;
+        memset(h->aq_host, 0, h->aq_cap);
+    } else if (h->aq_n) {
+        RLC_HIP(hipStreamSynchronize(h->st));     // a queued forward nobody fetched still reads / writes the buffer
+    }
+    h->aq_n = 0;
+    h->aq_flagged = flagged;
+    if (flagged) h->aq_seq += 1;
+    return 0;
+}
+
+// the completion word (null when the queued launch is not flagged); the kernel stores h->aq_seq into it
+int* rlc_h_aq_flag(rlc_handle* h) {
+    return h->aq_flagged ? (int*)(h->aq_host + h->aq_cap / sizeof(float) - 1) : nullptr;
+}
+
+// wait for the forward queued for agents [first_agent, first_agent + n); its outputs are then in h->aq_host
+int rlc_h_aq_wait(rlc_handle* h, int first_agent, int n) {
+    RLC_REQUIRE(h->aq_n > 0, "no acting forward is queued (rlc_*_act_queue)");
+    RLC_REQUIRE(first_agent == h->aq_first && n == h->aq_n, "queued forward is for agents [%d,%d), asked for [%d,%d)",
+                h->aq_first, h->aq_first + h->aq_n, first_agent, first_agent + n);
+    bool done = false;
+    if (h->aq_flagged) {
+        // spin on the completion word the kernel stores after its outputs (microseconds after the kernel ends; a stream
+        // synchronisation wakes up tens of microseconds later); bounded, then the ordinary wait
+        volatile int* flag = (volatile int*)(h->aq_host + h->aq_cap / sizeof(float) - 1);
+        for (long spin = 0; spin < 2000000L; spin++) {      // ~20 ms; a non-coherent mapping never shows the word: fall back
+            if (*flag == h->aq_seq) { done = true; break; }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    if (!done) RLC_HIP(hipStreamSynchronize(h->st));
+    h->aq_n = 0;
+    return 0;
+}
+
 int rlc_h_ensure_idx(rlc_handle* h, size_t count) {
     if (count > h->idx_cap) {
         RLC_HIP(hipStreamSynchronize(h->st));
@@ -533,26 +584,10 @@ int rlc_ddpg_act_queue(rlc_handle* h, int32_t first_agent, int32_t n, const doub
     RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->dv.n_agents, "agent range [%d,%d) invalid",
                 first_agent, first_agent + n);
     RLC_REQUIRE(states, "null array");
-    // Zero-copy: the acting kernel reads the states from, and stores the actions (and, for one agent, a completion word)
-    // into, pinned host memory -- no copy operations on the stream, one kernel launch.
-    const size_t S = h->dv.d.S, A = h->dv.d.A, need = sizeof(float) * (n * (S + A) + 4);
-    if (need > h->aq_cap) {
-        RLC_HIP(hipStreamSynchronize(h->st));
-        if (h->aq_host) RLC_HIP(hipHostFree(h->aq_host));
-        h->aq_host = nullptr; h->aq_cap = 0;
-        RLC_HIP(hipHostMalloc((void**)&h->aq_host, need * 2, hipHostMallocDefault));
-        h->aq_cap = need * 2;
-        memset(h->aq_host, 0, h->aq_cap);
-    } else if (h->aq_n) {
-        RLC_HIP(hipStreamSynchronize(h->st));     // a queued forward nobody fetched still reads / writes the buffer
-    }
-    h->aq_n = 0;
+    const size_t S = h->dv.d.S, A = h->dv.d.A;
+    if (rlc_h_aq_begin(h, n * (S + A), n == 1)) return 1;
     for (size_t i = 0; i < (size_t)n * S; i++) h->aq_host[i] = (float)states[i];
-    int* flag = (int*)(h->aq_host + h->aq_cap / sizeof(float) - 1);
-    h->aq_flagged = n == 1;
-    if (h->aq_flagged) h->aq_seq += 1;
-    if (rlc_launch_act(h->dv, first_agent, n, h->aq_host, h->aq_host + n * S, 0, h->st, h->aq_flagged ? flag : nullptr,
-                       h->aq_seq))
+    if (rlc_launch_act(h->dv, first_agent, n, h->aq_host, h->aq_host + n * S, 0, h->st, rlc_h_aq_flag(h), h->aq_seq))
         return 1;
     h->aq_first = first_agent; h->aq_n = n;
     return 0;
@@ -562,25 +597,8 @@ int rlc_ddpg_act_fetch(rlc_handle* h, int32_t first_agent, int32_t n, float* out
     RLC_NEED_DDPG(h);
     if (use_device(h)) return 1;
     RLC_REQUIRE(out_actions, "null array");
-    RLC_REQUIRE(h->aq_n > 0, "no acting forward is queued (rlc_ddpg_act_queue)");
-    RLC_REQUIRE(first_agent == h->aq_first && n == h->aq_n, "queued forward is for agents [%d,%d), asked for [%d,%d)",
-                h->aq_first, h->aq_first + h->aq_n, first_agent, first_agent + n);
-    bool done = false;
-    if (h->aq_flagged) {
-        // spin on the completion word the kernel stores after its actions (microseconds after the kernel ends; a stream
-        // synchronisation wakes up tens of microseconds later); bounded, then the ordinary wait
-        volatile int* flag = (volatile int*)(h->aq_host + h->aq_cap / sizeof(float) - 1);
-        for (long spin = 0; spin < 2000000L; spin++) {      // ~20 ms; a non-coherent mapping never shows the word: fall back
-            if (*flag == h->aq_seq) { done = true; break; }
-#if defined(__x86_64__)
-            __builtin_ia32_pause();
-#endif
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    }
-    if (!done) RLC_HIP(hipStreamSynchronize(h->st));
+    if (rlc_h_aq_wait(h, first_agent, n)) return 1;
     memcpy(out_actions, h->aq_host + (size_t)n * h->dv.d.S, sizeof(float) * n * h->dv.d.A);
-    h->aq_n = 0;
     return 0;
 }
 

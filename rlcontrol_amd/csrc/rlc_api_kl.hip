@@ -179,6 +179,12 @@ int rlc_kl_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* stat
                float* out_actions) {
     return rlc_sacfam_act(RLC_ALGO_KL, h, first_agent, n, states, sample, eps, out_actions);
 }
+int rlc_kl_act_queue(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps) {
+    return rlc_sacfam_act_queue(RLC_ALGO_KL, h, first_agent, n, states, sample, eps);
+}
+int rlc_kl_act_fetch(rlc_handle* h, int32_t first_agent, int32_t n, float* out_actions) {
+    return rlc_sacfam_act_fetch(RLC_ALGO_KL, h, first_agent, n, out_actions);
+}
 int rlc_kl_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps) {
     return rlc_sacfam_update(RLC_ALGO_KL, h, n_updates, host_indices, eps);
 }

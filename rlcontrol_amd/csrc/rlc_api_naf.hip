@@ -197,6 +197,36 @@ int rlc_naf_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* sta
     return 0;
 }
 
+// the acting forward queued behind the update that was just launched (see rlc_ddpg_act_queue, rlc_api.hip)
+int rlc_naf_act_queue(rlc_handle* h, int32_t first_agent, int32_t n, const double* states) {
+    RLC_NEED_NAF(h);
+    if (rlc_h_use_device(h)) return 1;
+    RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->naf.n_agents, "agent range [%d,%d) invalid",
+                first_agent, first_agent + n);
+    RLC_REQUIRE(states, "null array");
+    const size_t S = h->naf.d.S, A = h->naf.d.A, NL = A * (A + 1) / 2;
+    const size_t in_f = n * S, mu_f = n * A, lc_f = n * NL;
+    if (rlc_h_aq_begin(h, in_f + mu_f + lc_f, n == 1)) return 1;
+    for (size_t i = 0; i < in_f; i++) h->aq_host[i] = (float)states[i];
+    if (rlc_launch_naf_act(h->naf, first_agent, n, h->aq_host, h->aq_host + in_f, h->aq_host + in_f + mu_f, h->st,
+                           rlc_h_aq_flag(h), h->aq_seq))
+        return 1;
+    h->aq_first = first_agent; h->aq_n = n;
+    h->aq_out = in_f;
+    return 0;
+}
+
+int rlc_naf_act_fetch(rlc_handle* h, int32_t first_agent, int32_t n, float* out_mu, float* out_lcols) {
+    RLC_NEED_NAF(h);
+    if (rlc_h_use_device(h)) return 1;
+    RLC_REQUIRE(out_mu, "null array");
+    if (rlc_h_aq_wait(h, first_agent, n)) return 1;
+    const size_t A = h->naf.d.A, NL = A * (A + 1) / 2;
+    memcpy(out_mu, h->aq_host + h->aq_out, sizeof(float) * n * A);
+    if (out_lcols) memcpy(out_lcols, h->aq_host + h->aq_out + (size_t)n * A, sizeof(float) * n * NL);
+    return 0;
+}
+
 int rlc_naf_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices) {
     RLC_NEED_NAF(h);
     if (rlc_h_use_device(h)) return 1;

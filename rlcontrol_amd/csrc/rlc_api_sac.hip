@@ -235,11 +235,43 @@ int rlc_sacfam_act(int algo, rlc_handle* h, int32_t first_agent, int32_t n, cons
     float* dout = h->io_dev + in_f + eps_f;
     if ((algo == RLC_ALGO_KL ? rlc_launch_kl_act : rlc_launch_sac_act)(h->sac, first_agent, n, h->io_dev,
                                                                         eps_f ? h->io_dev + in_f : nullptr,
-                                                                        sample ? 1 : 0, dout, h->st))
+                                                                        sample ? 1 : 0, dout, h->st, nullptr, 0))
         return 1;
     RLC_HIP(hipMemcpyAsync(hin + in_f + eps_f, dout, sizeof(float) * out_f, hipMemcpyDeviceToHost, h->st));
     RLC_HIP(hipStreamSynchronize(h->st));
     memcpy(out_actions, hin + in_f + eps_f, sizeof(float) * out_f);
+    return 0;
+}
+
+// the acting forward queued behind the update that was just launched (see rlc_ddpg_act_queue, rlc_api.hip)
+int rlc_sacfam_act_queue(int algo, rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample,
+                         const float* eps) {
+    RLC_NEED_ALGO(h, algo);
+    if (rlc_h_use_device(h)) return 1;
+    RLC_REQUIRE(n >= 1 && first_agent >= 0 && first_agent + n <= h->sac.n_agents, "agent range [%d,%d) invalid",
+                first_agent, first_agent + n);
+    RLC_REQUIRE(states, "null array");
+    const size_t S = h->sac.d.S, A = h->sac.d.A;
+    const size_t in_f = n * S, eps_f = (sample && eps) ? n * A : 0, out_f = n * A;
+    if (rlc_h_aq_begin(h, in_f + eps_f + out_f, n == 1)) return 1;
+    for (size_t i = 0; i < in_f; i++) h->aq_host[i] = (float)states[i];
+    for (size_t i = 0; i < eps_f; i++) h->aq_host[in_f + i] = eps[i];
+    if ((algo == RLC_ALGO_KL ? rlc_launch_kl_act : rlc_launch_sac_act)(h->sac, first_agent, n, h->aq_host,
+                                                                        eps_f ? h->aq_host + in_f : nullptr, sample ? 1 : 0,
+                                                                        h->aq_host + in_f + eps_f, h->st, rlc_h_aq_flag(h),
+                                                                        h->aq_seq))
+        return 1;
+    h->aq_first = first_agent; h->aq_n = n;
+    h->aq_out = in_f + eps_f;
+    return 0;
+}
+
+int rlc_sacfam_act_fetch(int algo, rlc_handle* h, int32_t first_agent, int32_t n, float* out_actions) {
+    RLC_NEED_ALGO(h, algo);
+    if (rlc_h_use_device(h)) return 1;
+    RLC_REQUIRE(out_actions, "null array");
+    if (rlc_h_aq_wait(h, first_agent, n)) return 1;
+    memcpy(out_actions, h->aq_host + h->aq_out, sizeof(float) * n * h->sac.d.A);
     return 0;
 }
 
@@ -367,6 +399,12 @@ int rlc_sac_init_target(rlc_handle* h, int32_t agent) { return rlc_sacfam_init_t
 int rlc_sac_act(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps,
                 float* out_actions) {
     return rlc_sacfam_act(RLC_ALGO_SAC, h, first_agent, n, states, sample, eps, out_actions);
+}
+int rlc_sac_act_queue(rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample, const float* eps) {
+    return rlc_sacfam_act_queue(RLC_ALGO_SAC, h, first_agent, n, states, sample, eps);
+}
+int rlc_sac_act_fetch(rlc_handle* h, int32_t first_agent, int32_t n, float* out_actions) {
+    return rlc_sacfam_act_fetch(RLC_ALGO_SAC, h, first_agent, n, out_actions);
 }
 int rlc_sac_update(rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps) {
     return rlc_sacfam_update(RLC_ALGO_SAC, h, n_updates, host_indices, eps);

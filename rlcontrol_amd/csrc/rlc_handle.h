@@ -25,6 +25,7 @@ struct rlc_handle {
     float* aq_dev; float* aq_host; size_t aq_cap;   // device / pinned host staging: [n][S] states then [n][A] actions
     int aq_first, aq_n;                  // agent range of the queued forward; aq_n == 0: nothing queued
     int aq_seq;                          // completion flag protocol of one-agent forwards: the kernel stores ++aq_seq
+    size_t aq_out;                       // float offset of the queued forward's outputs in aq_host
     bool aq_flagged;                     // the queued forward reports through the flag word (aq_host[aq_cap / 4 - 1])
     long long* idx_pin; size_t idx_pin_cap;   // pinned, device-readable index staging for small host-index updates
     hipEvent_t idx_ev; bool idx_ev_armed;     // recorded behind the launch that reads idx_pin
@@ -89,6 +90,9 @@ int rlc_sacfam_get_blob(int algo, rlc_handle* h, int32_t agent, int32_t which, f
 int rlc_sacfam_init_target(int algo, rlc_handle* h, int32_t agent);
 int rlc_sacfam_act(int algo, rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample,
                    const float* eps, float* out_actions);
+int rlc_sacfam_act_queue(int algo, rlc_handle* h, int32_t first_agent, int32_t n, const double* states, int32_t sample,
+                         const float* eps);
+int rlc_sacfam_act_fetch(int algo, rlc_handle* h, int32_t first_agent, int32_t n, float* out_actions);
 int rlc_sacfam_update(int algo, rlc_handle* h, int32_t n_updates, const int64_t* host_indices, const float* eps);
 int rlc_sacfam_update_batch(int algo, rlc_handle* h, int32_t agent, int32_t batch, const double* states,
                             const double* actions, const double* next_states, const double* rewards,
@@ -100,6 +104,10 @@ int rlc_sacfam_last_tap(int algo, rlc_handle* h, int32_t agent, int32_t which, f
 // shared helpers (rlc_api.hip)
 int rlc_h_check_agent(const rlc_handle* h, int agent);
 int rlc_h_use_device(const rlc_handle* h);
+// queued acting forward (rlc_api.hip): pinned staging + completion word
+int rlc_h_aq_begin(rlc_handle* h, size_t floats, bool flagged);
+int* rlc_h_aq_flag(rlc_handle* h);
+int rlc_h_aq_wait(rlc_handle* h, int first_agent, int n);
 int rlc_h_ensure_io(rlc_handle* h, size_t bytes);
 int rlc_h_ensure_idx(rlc_handle* h, size_t count);
 int rlc_h_init_common(rlc_handle* h, int algo, int device, int n_agents, int S, int A, int B, long long cap,

@@ -113,8 +113,8 @@ int rlc_launch_kl_update_mfma(const RlcSacDev& dv, int first_agent, int n_agents
                               const long long* idx_dev, const float* eps_dev, int grad_taps, hipStream_t st,
                               const RlcSacRollout* rollout = nullptr);
 int rlc_launch_kl_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
-                      int sample, float* out_dev, hipStream_t st);
+                      int sample, float* out_dev, hipStream_t st, int* done_flag = nullptr, int done_val = 0);
 int rlc_launch_sac_eval(const RlcSacDev& dv, const RlcEnvDev& env, int eval_round, hipStream_t st);
 // one state per agent; sample = 0 mean action, 1 reparameterised sample (eps_dev [n][A] or null -> Philox)
 int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
-                       int sample, float* out_dev, hipStream_t st);
+                       int sample, float* out_dev, hipStream_t st, int* done_flag = nullptr, int done_val = 0);

@@ -366,8 +366,11 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_kernel(RlcSacDev dv_a
 }
 
 // mean / sampled action for one state per agent (sac_network.py:327-343): one workgroup per agent
+// done_flag (or null): a word in host-visible memory that receives done_val once the launch's actions are stored
+// (rlc_sac_act_queue; see rlc_ddpg_act_kernel)
 __global__ __launch_bounds__(kThreads) void rlc_sac_act_kernel(RlcSacDev dv, int first_agent, const float* states,
-                                                               const float* eps_in, int sample, float* out) {
+                                                               const float* eps_in, int sample, float* out,
+                                                               int* done_flag, int done_val) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const RlcSacDims d = dv.d;
     const int S = d.S, A = d.A;
@@ -381,6 +384,13 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_act_kernel(RlcSacDev dv, int
     sac_policy_forward(d, th, L, dv.amax0, sample);
     if (tid < A) out[(size_t)blockIdx.x * A + tid] = L.out[tid];
     if (sample && !eps_in && tid == 0) dv.noise_ctr[agent] += 1;
+    if (done_flag) {                                // (queued forward of a drop-in agent: one workgroup)
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence_system();                     // the output stores first
+            __hip_atomic_store(done_flag, done_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // evaluation of the on-device loop: one greedy (mean-action) test episode per workgroup
@@ -451,10 +461,11 @@ int rlc_launch_sac_update(const RlcSacDev& dv, int first_agent, int n_agents, in
 }
 
 int rlc_launch_sac_act(const RlcSacDev& dv, int first_agent, int n, const float* states_dev, const float* eps_dev,
-                       int sample, float* out_dev, hipStream_t st) {
+                       int sample, float* out_dev, hipStream_t st, int* done_flag, int done_val) {
     const size_t lds = sizeof(float) * sac_policy_lds_floats(dv.d);
+    RLC_REQUIRE(done_flag == nullptr || n == 1, "a completion flag needs a one-workgroup acting launch");
     hipLaunchKernelGGL(rlc_sac_act_kernel, dim3(n), dim3(kThreads), lds, st, dv, first_agent, states_dev, eps_dev,
-                       sample, out_dev);
+                       sample, out_dev, done_flag, done_val);
     RLC_HIP(hipGetLastError());
     return 0;
 }

@@ -132,6 +132,19 @@ class KLPopulation(Population):
                                    ctypes.c_int32(1 if sample else 0), fptr(e) if e is not None else None, fptr(out)))
         return out
 
+    def act_queue(self, states, first_agent=0, sample=False, eps=None):
+        """queue the acting forward for `states` behind the work already on the handle's stream (no synchronisation)"""
+        s = f64(states).reshape(-1, self.S)
+        e = None if eps is None else np.ascontiguousarray(eps, np.float32).reshape(s.shape[0], self.A)
+        check(self._lib.rlc_kl_act_queue(self._h, int(first_agent), ctypes.c_int32(s.shape[0]), dptr(s),
+                                          ctypes.c_int32(1 if sample else 0), fptr(e) if e is not None else None))
+        return s.shape[0]
+
+    def act_fetch(self, n, first_agent=0):
+        out = np.empty((int(n), self.A), np.float32)
+        check(self._lib.rlc_kl_act_fetch(self._h, int(first_agent), ctypes.c_int32(int(n)), fptr(out)))
+        return out
+
     def update(self, n_updates=1, host_indices=None, eps=None):
         idx = None
         if host_indices is not None:

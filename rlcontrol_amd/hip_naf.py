@@ -108,6 +108,18 @@ class NAFPopulation(Population):
                                     fptr(lc) if lc is not None else None))
         return (mu, lc) if with_lcols else mu
 
+    def act_queue(self, states, first_agent=0):
+        """queue the greedy forward (mu and the L columns) for `states` behind the work already on the handle's stream"""
+        s = f64(states).reshape(-1, self.S)
+        check(self._lib.rlc_naf_act_queue(self._h, int(first_agent), ctypes.c_int32(s.shape[0]), dptr(s)))
+        return s.shape[0]
+
+    def act_fetch(self, n, first_agent=0):
+        mu = np.empty((int(n), self.A), np.float32)
+        lc = np.empty((int(n), self.A * (self.A + 1) // 2), np.float32)
+        check(self._lib.rlc_naf_act_fetch(self._h, int(first_agent), ctypes.c_int32(int(n)), fptr(mu), fptr(lc)))
+        return mu, lc
+
     def update(self, n_updates=1, host_indices=None):
         idx = None
         if host_indices is not None:

@@ -136,6 +136,37 @@ def test_queued_next_action_equals_plain_acting(hip_lib):
     assert np.all(np.isfinite(outs[0]))
 
 
+_OTHER_AGENTS = {
+    "SoftActorCritic": {"exploration_policy": "none", "actor_l1_dim": 128, "actor_l2_dim": 128, "critic_l1_dim": 128,
+                        "critic_l2_dim": 128, "pi_lr": 1e-3, "qf_vf_lr": 1e-3, "entropy_scale": 0.1,
+                        "sample_for_eval": "True", "use_true_q": "False"},
+    "NAF": {"exploration_policy": "none", "l1_dim": 200, "l2_dim": 200, "noise_scale": 0.3, "learning_rate": 1e-3},
+    "ReverseKL": {"exploration_policy": "none", "actor_l1_dim": 64, "actor_l2_dim": 64, "critic_l1_dim": 64,
+                  "critic_l2_dim": 64, "pi_lr": 1e-3, "qf_vf_lr": 1e-3, "entropy_scale": 0.1, "sample_for_eval": "True",
+                  "use_true_q": "False", "l_param": 6, "N_param": 32, "optim_type": "intg", "q_update_type": "non_sac"},
+}
+
+
+@pytest.mark.parametrize("name", sorted(_OTHER_AGENTS))
+def test_queued_next_action_of_the_other_agents(hip_lib, name):
+    """rlc_sac_/rlc_kl_/rlc_naf_act_queue + _fetch: same actions, step for step, as the un-queued agent -- including the
+    host random streams (the training sample's eps is drawn at queue time and put back when the forward is dropped:
+    _drive interleaves evaluation calls that sample too, sample_for_eval = "True")."""
+    from rlcontrol_amd.utils.main_utils import create_agent
+    outs = []
+    for queued in (True, False):
+        cfg, env = _config(5, 32)
+        cfg.merge_config(_OTHER_AGENTS[name])
+        agent = create_agent(name, cfg)
+        assert agent.network_manager.queues_next_action
+        acts, fetched = _drive(agent, env, 5, 90, queued)
+        outs.append(acts)
+        if queued:
+            assert fetched == 90 - 32
+    assert np.array_equal(outs[0], outs[1])
+    assert np.all(np.isfinite(outs[0]))
+
+
 def test_act_fetch_without_queue_is_refused(hip_lib):
     from rlcontrol_amd._lib import RlcError
     from rlcontrol_amd.hip_ddpg import DDPGPopulation
