@@ -344,10 +344,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                     const int p = (u.g == 0) ? d.oWc3 + n : d.obc2 + n;
                     const float gr = (u.g == 0) ? g_wc3[i] : g_bc2[i];
                     float mm = m_c[p], vv = v_c[p];
+                    const float o = tt[p];              // (with the other loads: one memory round trip, not two)
                     const float nv = adam_step(th[p], gr, mm, vv, alpha_c);
                     m_c[p] = mm; v_c[p] = vv; th[p] = nv;
                     if (tap_gc) tap_gc[p] = gr;
-                    const float o = tt[p];
                     tt[p] = o + tau * (nv - o);
                 }
             }
@@ -359,10 +359,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                 if (u.lane == 0) {
                     const int p = d.obc3;
                     float mm = m_c[p], vv = v_c[p];
+                    const float o = tt[p];              // (with the other loads: one memory round trip, not two)
                     const float nv = adam_step(th[p], gr, mm, vv, alpha_c);
                     m_c[p] = mm; v_c[p] = vv; th[p] = nv;
                     if (tap_gc) tap_gc[p] = gr;
-                    const float o = tt[p];
                     tt[p] = o + tau * (nv - o);
                 }
             }
@@ -501,10 +501,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                     for (int j = 0; j < AD; j++)
                         if (u.g == j + 1) { p = d.oWa3 + n * AD + j; gr = g_wa3[i][j]; }
                     float mm = m_a[p], vv = v_a[p];
+                    const float o = tt[p];              // (with the other loads: one memory round trip, not two)
                     const float nv = adam_step(th[p], gr, mm, vv, alpha_a);
                     m_a[p] = mm; v_a[p] = vv; th[p] = nv;
                     if (tap_ga) tap_ga[p] = gr;
-                    const float o = tt[p];
                     tt[p] = o + tau * (nv - o);
                 }
             }
@@ -517,10 +517,10 @@ __global__ __launch_bounds__(kThreads) void rlc_ddpg_update_mfma_kernel(RlcDev d
                 if (u.lane == 0) {
                     const int p = d.oba3 + j;
                     float mm = m_a[p], vv = v_a[p];
+                    const float o = tt[p];              // (with the other loads: one memory round trip, not two)
                     const float nv = adam_step(th[p], gr, mm, vv, alpha_a);
                     m_a[p] = mm; v_a[p] = vv; th[p] = nv;
                     if (tap_ga) tap_ga[p] = gr;
-                    const float o = tt[p];
                     tt[p] = o + tau * (nv - o);
                 }
             }

@@ -1349,11 +1349,12 @@ struct Blk {
                         tap[p] = gr;
                     } else {
                         float mm = m[p], vv = v[p];
+                        const float o = tt ? tt[p] : 0.0f;          // with the other loads: one memory round trip, not two
                         const float nv = astep_small(th[p], gr, mm, vv, alpha);
                         m[p] = mm; v[p] = vv; th[p] = nv;
                         if (stage) stage[is_bias ? S * H1 + k : s * H1 + k] = nv;
                         if (tap) tap[p] = gr;
-                        if (tt) tt[p] = polyak(tt[p], nv, tau);
+                        if (tt) tt[p] = polyak(o, nv, tau);
                     }
                 }
             }
@@ -1668,10 +1669,12 @@ struct Blk {
                         const size_t p = rlc_blk_index(((H1 + 15) & ~15) + j, n, N);   // first extra block row + j
                         if constexpr (GONLY) { tapp[p] = gr; continue; }
                         float mm = mp[p], vv = vp[p];
+                        float o = 0.0f;
+                        if constexpr (!NOPOL) o = Wt[p];
                         const float nv = astep_small(Wp[p], gr, mm, vv, alpha);
                         mp[p] = mm; vp[p] = vv; Wp[p] = nv;
                         if (tapp) tapp[p] = gr;
-                        if constexpr (!NOPOL) Wt[p] = polyak(Wt[p], nv, tau);
+                        if constexpr (!NOPOL) Wt[p] = polyak(o, nv, tau);
                     }
                 }
             }
@@ -1686,19 +1689,21 @@ struct Blk {
     __device__ __forceinline__ void adam_scalar_m(float* th, float* m, float* v, float* tt, float* tap, int p, float gr,
                                                   float alpha, float tau) const {
         float mm = m[p], vv = v[p];
+        const float o = tt ? tt[p] : 0.0f;          // with the other loads: one memory round trip, not two
         const float nv = astep_small(th[p], gr, mm, vv, alpha);
         m[p] = mm; v[p] = vv; th[p] = nv;
         if (tap) tap[p] = gr;
-        if (tt) tt[p] = polyak(tt[p], nv, tau);
+        if (tt) tt[p] = polyak(o, nv, tau);
     }
     // Adam (+ Polyak) on one scalar parameter by the calling lane
     __device__ __forceinline__ static void adam_scalar(float* th, float* m, float* v, float* tt, float* tap, int p,
                                                        float gr, float alpha, float tau) {
         float mm = m[p], vv = v[p];
+        const float o = tt ? tt[p] : 0.0f;
         const float nv = adam_step(th[p], gr, mm, vv, alpha);
         m[p] = mm; v[p] = vv; th[p] = nv;
         if (tap) tap[p] = gr;
-        if (tt) tt[p] = polyak(tt[p], nv, tau);
+        if (tt) tt[p] = polyak(o, nv, tau);
     }
 };
 

@@ -142,7 +142,12 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
     float* mm = dv.m + (size_t)agent * d.Ppad;
     float* vv = dv.v + (size_t)agent * d.Ppad;
     float* pw = dv.pw + agent * 4;
+#ifdef RLC_STAMPS
+    float* stamp_buf = grad_taps ? dv.tap_g + (size_t)agent * d.Ppad : nullptr;   // diagnostic build: no gradient taps
+    float* tapg = nullptr;
+#else
     float* tapg = grad_taps ? dv.tap_g + (size_t)agent * d.Ppad : nullptr;
+#endif
     const float alpha_ent = dv.alpha[agent], amax0 = dv.amax0, tau = dv.tau;
     const float EPS = 1e-6f, LOG2PI = 1.8378770664093453f, HALF_RANGE = 0.5f * (2.0f - (-20.0f));
     const float invB = 1.0f / (float)B;
@@ -161,7 +166,26 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
 
     stagger_start();
     f32x4 acc[MT][NTW];
+#ifdef RLC_STAMPS
+    // diagnostic build only: phase boundaries in shader cycles (scripts/phase_stamps_sac.py), written where the gradient tap lives
+    long long t_prev = clock64();
+    int stamp_i = 0;
+#define STAMP()                                                                                  \
+    do {                                                                                         \
+        if (tid == 0 && stamp_buf) { const long long t = clock64(); stamp_buf[stamp_i] += (float)(t - t_prev); t_prev = t; } \
+        stamp_i++;                                                                               \
+    } while (0)
+    if (stamp_buf) for (int i = tid; i < 64; i += kThreads) stamp_buf[i] = 0.0f;
+    u.stamp_buf = stamp_buf;
+    __syncthreads();
+#else
+#define STAMP() do {} while (0)
+#endif
     for (int upd = 0; upd < n_updates; upd++) {
+#ifdef RLC_STAMPS
+        stamp_i = 0;
+        if (tid == 0) t_prev = clock64();
+#endif
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));     // see ddpg_mfma_kernel.h
         if (rollout) {
             // on-device experiment loop: one environment step first; update when learn() would run
@@ -233,6 +257,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         lds_barrier();
         if (tid == 0 && !eps_in) dv.noise_ctr[agent] = nctr + 1;
 
+        STAMP();
         // ================= 1: V'(s') from the target network (sac_network.py:107) =================
         u.H1 = L1C;
 #ifdef RLC_W1_STAGE
@@ -246,6 +271,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         u.template row_dot<false, 1>(acc, L2C, [&](int n, int) { return tt[d.vW3 + n]; }, L.part_q);
         lds_barrier();
         for (int b = tid; b < B; b += kThreads) L.vt[b] = u.template part_sum<1>(L.part_q, b, 0) + tt[d.vb3];
+        STAMP();
         // ================= 2: the hidden contraction of Q, shared by Q(s,a) and Q(s,pi) =================
 #ifdef RLC_W1_STAGE
         u.trunk((const lds_f32*)L.w1q, (const lds_f32*)(L.w1q + S * L1C), L.x);
@@ -256,6 +282,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         f32x4 accq[MT][NTW];
         u.fwd_gemm(accq, th + d.qW2, L2C, L1C);
         lds_barrier();                 // every wave is done reading hbuf = qh1
+        STAMP();
         // ================= 3: pi forward (sac_network.py:234-301) =================
         u.H1 = L1A;
 #ifdef RLC_W1_STAGE
@@ -298,6 +325,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             dv.tap_logp[(size_t)agent * RLC_MAX_BATCH + b] = lp;
         }
         lds_barrier();
+        STAMP();
         // ================= 4: Q(s,pi), dQ/da, Q(s,a) from the parked contraction =================
         u.template concat_head_dots<AD>(accq, th + d.qb2, L2C, L.api, th + d.qW2, d.arow0, th + d.qW3, L.part_p);
         u.template bias_relu<AD>(accq, th + d.qb2, L2C, L.a, th + d.qW2, d.arow0);
@@ -358,6 +386,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
                 g_qb2[i] = col4_sum(s2);
             }
         }
+        STAMP();
         // ================= 5: pi step =================
         float g_ph[NTW][NS], g_pb2[NTW];
         {
@@ -404,7 +433,9 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
 #endif
         u.template bwd_gemm<NS, 0>(acc, th + d.pW2, L2A, L1A, L.dml, L.wvec);
         lds_barrier();
+        STAMP();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_p, d.pW1, d.pb1, tapg, tt, tau, L.xc);
+        STAMP();
         u.template wgrad_adam_pre<NS, 0, 0, false, false, NPRE>(L.dml, nullptr, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, alpha_p,
                                         tapg ? tapg + d.pW2 : nullptr, tt + d.pW2, tau, L.wvec, pre);
         {
@@ -435,6 +466,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             }
         }
         lds_barrier();
+        STAMP();
         // ================= 6: Q step =================
         u.H1 = L1C;
 #ifdef RLC_W1_STAGE
@@ -449,7 +481,9 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
 #endif
         u.template bwd_gemm<1, 1>(acc, th + d.qW2, L2C, L1C, L.dout, L.wvec);
         lds_barrier();
+        STAMP();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_v, d.qW1, d.qb1, tapg, tt, tau, L.x);
+        STAMP();
         u.template wgrad_adam_pre<1, AD, 1, false, false, NPRE>(L.dout, L.a, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, alpha_v,
                                         tapg ? tapg + d.qW2 : nullptr, tt + d.qW2, tau, L.wvec, pre);
         {
@@ -471,6 +505,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             }
         }
         lds_barrier();
+        STAMP();
         // ================= 7: V forward + step =================
 #ifdef RLC_W1_STAGE
         u.trunk((const lds_f32*)L.w1v, (const lds_f32*)(L.w1v + S * L1C), L.xc);
@@ -534,7 +569,9 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
 #endif
         u.template bwd_gemm<1, 0>(acc, th + d.vW2, L2C, L1C, L.dvs, L.wvec);
         lds_barrier();
+        STAMP();
         u.trunk_grad_adam(acc, th, mm, vv, alpha_v, d.vW1, d.vb1, tapg, tt, tau, L.xc);
+        STAMP();
         u.template wgrad_adam_pre<1, 0, 0, false, false, NPRE>(L.dvs, nullptr, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, alpha_v,
                                        tapg ? tapg + d.vW2 : nullptr, tt + d.vW2, tau, L.wvec, pre);
         {
@@ -556,9 +593,11 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             }
         }
         __syncthreads();
+        STAMP();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; pw[2] *= 0.9f; pw[3] *= 0.999f; }
         __syncthreads();
     }
+#undef STAMP
 }
 
 template <int MT, int NTW, int AD, bool T4>
