@@ -1464,7 +1464,16 @@ struct Blk {
         };
         // EXACT: the item has exactly MCC tiles (no aliased rows): the MCC activation reads of a k-step are then
         // base + q * 64 B with a compile-time stride and pair up as ds_read2_b32
+        // RLC_WG_LATE_ISSUE (per translation unit): the OTHER register set is loaded for item `nxt` after this item's
+        // k-loop instead of before it, and handed back by value -- a wave with two items per matrix (widths <= 128) then
+        // issues its second prefetch when the first has landed instead of queueing both behind each other up front
+#ifdef RLC_WG_LATE_ISSUE
+#define RLC_RUN_RET return Q
+        auto run = [&](const WgPre& P, int idx, int nxt, auto mcc_tag, auto exact_tag) {
+#else
+#define RLC_RUN_RET return
         auto run = [&](const WgPre& P, int idx, auto mcc_tag, auto exact_tag) {
+#endif
             constexpr int MCC = decltype(mcc_tag)::value;
             constexpr bool EXACT = decltype(exact_tag)::value;
             int t, m0, nq;
@@ -1538,6 +1547,16 @@ struct Blk {
             else if (LDH == 136) kloop(std::integral_constant<int, 136>{});
             else kloop(std::integral_constant<int, 0>{});
             sub_stamp(22);
+#ifdef RLC_WG_LATE_ISSUE
+            WgPre Q;
+            asm volatile("" ::: "memory");
+            if (nxt >= 0) issue(Q, nxt);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) Q.w[q] = Q.m[q] = Q.v[q] = Q.t[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("" ::: "memory");
+#endif
             const bool n4ok = 16 * t + 4 * g < N;
             // Every prefetched register of the item is demanded HERE, before the first store of the epilogue.  gfx9's
             // vmcnt counts stores as well as loads, in issue order, and hipcc derives each tile's wait from the loads
@@ -1556,7 +1575,7 @@ struct Blk {
 #pragma unroll
                 for (int q = 0; q < MCC; q++)
                     if (acc[q][0] == 1.2345e33f) Wp[0] = acc[q][1] + acc[q][2] + acc[q][3];
-                return;
+                RLC_RUN_RET;
             }
 #pragma unroll
             for (int q = 0; q < MCC; q++) {
@@ -1592,19 +1611,28 @@ struct Blk {
                 }
             }
             sub_stamp(23);
+            RLC_RUN_RET;
         };
+#undef RLC_RUN_RET
+#ifdef RLC_WG_LATE_ISSUE
+#define RLC_RUN(P, idx, ...) return run(P, idx, nxt, __VA_ARGS__)
+        auto run_any = [&](const WgPre& P, int idx, int nxt) {
+#else
+#define RLC_RUN(P, idx, ...) run(P, idx, __VA_ARGS__)
         auto run_any = [&](const WgPre& P, int idx) {
+#endif
             const int ch = idx / NT;
             const int nq = cbase + (ch < crem ? 1 : 0);
 #ifndef RLC_WG_EXACT      // per translation unit: +4 % for SoftActorCritic (widths <= 128), -1.5 % for DDPG (register pressure)
-            if (nq == 4) run(P, idx, std::integral_constant<int, 4>{}, std::false_type{});
-            else run(P, idx, std::integral_constant<int, 3>{}, std::false_type{});
+            if (nq == 4) RLC_RUN(P, idx, std::integral_constant<int, 4>{}, std::false_type{});
+            else RLC_RUN(P, idx, std::integral_constant<int, 3>{}, std::false_type{});
 #else
-            if (nq == 4) run(P, idx, std::integral_constant<int, 4>{}, std::true_type{});
-            else if (nq == 3) run(P, idx, std::integral_constant<int, 3>{}, std::true_type{});
-            else run(P, idx, std::integral_constant<int, 3>{}, std::false_type{});      // chunks of < 3 tiles alias tile 0 (never stored)
+            if (nq == 4) RLC_RUN(P, idx, std::integral_constant<int, 4>{}, std::true_type{});
+            else if (nq == 3) RLC_RUN(P, idx, std::integral_constant<int, 3>{}, std::true_type{});
+            else RLC_RUN(P, idx, std::integral_constant<int, 3>{}, std::false_type{});      // chunks of < 3 tiles alias tile 0 (never stored)
 #endif
         };
+#undef RLC_RUN
 
         WgPre PA, PB;
         int idx = wave;
@@ -1623,6 +1651,19 @@ struct Blk {
         if constexpr (NPRE > 0) { PA = pre.a; if constexpr (NPRE > 1) PB = pre.b; }      // already in flight (wgrad_prefetch)
         else if (idx < nitems) issue(PA, idx);
         sub_stamp(21);
+#ifdef RLC_WG_LATE_ISSUE
+        while (idx < nitems) {
+            RLC_CBAR();
+            PB = run_any(PA, idx, idx + kWaves < nitems ? idx + kWaves : -1);
+            RLC_CBAR();
+            idx += kWaves;
+            if (idx >= nitems) break;
+            PA = run_any(PB, idx, idx + kWaves < nitems ? idx + kWaves : -1);
+            RLC_CBAR();
+            idx += kWaves;
+        }
+        (void)first;
+#else
         while (idx < nitems) {
             RLC_CBAR();
             if (idx + kWaves < nitems && !(NPRE > 1 && first)) issue(PB, idx + kWaves);
@@ -1638,6 +1679,7 @@ struct Blk {
             RLC_CBAR();
             idx += kWaves;
         }
+#endif
 #undef RLC_CBAR
         sub_begin();
         // extra rows of a concat layer (rank-NE term): G[H1+j][n] = sum_b E[b][j] * D[b][n]; one N tile per

@@ -3,6 +3,9 @@
 #ifndef RLC_WG_NO_EXACT
 #define RLC_WG_EXACT 1      // mfma_blocks.h wgrad_adam: paired activation reads in exact items (+4 % at widths <= 128)
 #endif
+#ifndef RLC_WG_NO_LATE_ISSUE
+#define RLC_WG_LATE_ISSUE 1 // mfma_blocks.h wgrad_adam: second prefetch issued after the first k-loop (+4.5 % at widths <= 128;
+#endif                      // DDPG +-0, NAF -1.6 %: profiles/r03_variant_timings_s27.txt)
 #include "sac_mfma_kernel.h"
 
 #ifndef RLC_MT

@@ -426,8 +426,8 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         // under the backward GEMM, not under one k-loop (RLC_NO_EARLY_PREFETCH: the round-2 order, for A/B runs)
         typename U::WgPre2 pre;
 #ifdef RLC_EARLY_PREFETCH
-        constexpr int NPRE = 2;
-        u.wgrad_prefetch(pre, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, tt + d.pW2);
+        constexpr int NPRE = (RLC_EARLY_PREFETCH + 0) >= 2 ? 2 : 1;      // -DRLC_EARLY_PREFETCH=<sets in flight>
+        u.template wgrad_prefetch<false, NPRE>(pre, L2A, th + d.pW2, mm + d.pW2, vv + d.pW2, tt + d.pW2);
 #else
         constexpr int NPRE = 0;
 #endif
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
         for (int n = tid; n < 256; n += kThreads) L.wvec[n] = n < L2C ? th[d.qW3 + n] : 0.0f;
         lds_barrier();
 #ifdef RLC_EARLY_PREFETCH
-        u.wgrad_prefetch(pre, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, tt + d.qW2);
+        u.template wgrad_prefetch<false, NPRE>(pre, L2C, th + d.qW2, mm + d.qW2, vv + d.qW2, tt + d.qW2);
 #endif
         u.template bwd_gemm<1, 1>(acc, th + d.qW2, L2C, L1C, L.dout, L.wvec);
         lds_barrier();
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(kThreads) void rlc_sac_update_mfma_kernel(RlcSacDev
             }
         }
 #ifdef RLC_EARLY_PREFETCH
-        u.wgrad_prefetch(pre, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, tt + d.vW2);
+        u.template wgrad_prefetch<false, NPRE>(pre, L2C, th + d.vW2, mm + d.vW2, vv + d.vW2, tt + d.vW2);
 #endif
         u.template bwd_gemm<1, 0>(acc, th + d.vW2, L2C, L1C, L.dvs, L.wvec);
         lds_barrier();
