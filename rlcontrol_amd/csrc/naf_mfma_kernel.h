@@ -113,7 +113,12 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
     float* mm = dv.m + (size_t)agent * d.Ppad;
     float* vv = dv.v + (size_t)agent * d.Ppad;
     float* pw = dv.pw + agent * 2;
+#ifdef RLC_STAMPS
+    float* stamp_buf = grad_taps ? dv.tap_g + (size_t)agent * d.Ppad : nullptr;   // diagnostic build: no gradient taps
+    float* tapg = nullptr;
+#else
     float* tapg = grad_taps ? dv.tap_g + (size_t)agent * d.Ppad : nullptr;
+#endif
     const float tau = dv.tau;
     float amax[AD];
 #pragma unroll
@@ -132,7 +137,26 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
 
     stagger_start();
     f32x4 acc[MT][NTW];
+#ifdef RLC_STAMPS
+    // diagnostic build only: phase boundaries in shader cycles (scripts/phase_stamps_naf.py), written where the gradient tap lives
+    long long t_prev = clock64();
+    int stamp_i = 0;
+#define STAMP()                                                                                  \
+    do {                                                                                         \
+        if (tid == 0 && stamp_buf) { const long long t = clock64(); stamp_buf[stamp_i] += (float)(t - t_prev); t_prev = t; } \
+        stamp_i++;                                                                               \
+    } while (0)
+    if (stamp_buf) for (int i = tid; i < 64; i += kThreads) stamp_buf[i] = 0.0f;
+    u.stamp_buf = stamp_buf;
+    __syncthreads();
+#else
+#define STAMP() do {} while (0)
+#endif
     for (int upd = 0; upd < n_updates; upd++) {
+#ifdef RLC_STAMPS
+        stamp_i = 0;
+        if (tid == 0) t_prev = clock64();
+#endif
         asm volatile("" : "+v"(u.c), "+v"(u.g), "+s"(u.wave));     // see ddpg_mfma_kernel.h
         if (rollout) {
             // on-device experiment loop: one environment step first; update when learn() would run
@@ -169,6 +193,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         }
         lds_barrier();
 
+        STAMP();
         // ================= 1: target V'(s') and the float64 TD glue (agents/NAF.py:70) =================
         u.trunk(tt + d.W1, tt + d.b1, L.x2);
         lds_barrier();
@@ -182,6 +207,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             L.y[b] = y;
             dv.tap_y[(size_t)agent * RLC_MAX_BATCH + b] = y;
         }
+        STAMP();
         // ================= 2: online forward =================
         u.trunk(th + d.W1, th + d.b1, L.x);
         for (int i = tid; i < (AD + 1) * 256; i += kThreads) {      // rows < A: Wa3 transposed; row A: Wv3
@@ -241,6 +267,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         u.template row_dot<false, 1>(acc, L2, [&](int n, int) { return wv3[n]; }, L.part_v);
         u.template store_masks<1, false>(acc, L2);
         lds_barrier();
+        STAMP();
         // ================= 3: per sample: L columns, advantage, Q, and the seeds of every head's gradient =================
         for (int b = tid; b < B; b += kThreads) {
             float diff[AD], ddiff[AD], tanhv[AD];
@@ -289,6 +316,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             for (int j = 0; j < AD; j++) L.dz[b * AD + j] = -ddiff[j] * amax[j] * (1.0f - tanhv[j] * tanhv[j]);
         }
         lds_barrier();
+        STAMP();
         // ================= 4: output-layer / bias gradients from the live accumulators =================
         float g_wa3[NTW][AD], g_ba2[NTW], g_wv3[NTW], g_bv2[NTW];
         {
@@ -330,6 +358,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
                 g_bv2[i] = col4_sum(sv2);
             }
         }
+        STAMP();
         // ================= 5: d trunk = V branch (rank one) + mu branch (accumulated) + heads =================
         const float alpha = adam_alpha(dv.lr[agent], pw[0], pw[1]);
         u.template bwd_gemm<1, 1, false>(acc, th + d.Wv2, L2, L1, L.dV, wv3);
@@ -345,7 +374,9 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
         constexpr int NPRE = 0;
 #endif
         // heads off the trunk: dL/dh1[b][k] += sum_j dhd[b][j] * wh[j][k]  (dhd / wh rows beyond the NH heads in use are zero)
+        STAMP();
         u.trunk_grad_adam(acc, th, mm, vv, alpha, d.W1, d.b1, tapg, tt, tau, L.x, HeadExtra{L.dhd, L.wh});
+        STAMP();
         // head weights: g[k][j] = sum_b h1[b][k] dhd[b][j] (thread k), head biases (wave j)
         for (int k = tid; k < L1; k += kThreads) {
             float gs[NH];
@@ -376,6 +407,7 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
                 U::adam_scalar(th, mm, vv, tt, tapg, ob, gr, alpha, tau);
             }
         }
+        STAMP();
         // ================= 6: the two L1 x L2 matrices, Adam + Polyak in the GEMM epilogues =================
         u.template wgrad_adam_pre<AD, 0, 0, false, false, NPRE>(L.dz, nullptr, L2, th + d.Wa2, mm + d.Wa2, vv + d.Wa2, alpha,
                                         tapg ? tapg + d.Wa2 : nullptr, tt + d.Wa2, tau, L.wvec, pre);
@@ -411,9 +443,11 @@ __global__ __launch_bounds__(kThreads) void rlc_naf_update_mfma_kernel(RlcNafDev
             }
         }
         __syncthreads();
+        STAMP();
         if (tid == 0) { pw[0] *= 0.9f; pw[1] *= 0.999f; }
         __syncthreads();
     }
+#undef STAMP
 }
 
 template <int MT, int NTW, int AD, bool T4>
