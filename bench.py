@@ -416,6 +416,8 @@ def main():
             "config": {"workload": "DDPG on synthetic Pendulum-shaped replay (1e6 transitions/agent), obs=3 act=1 "
                                    "l1=l2=200 batch=100, fused HIP replay-sample+gather+update kernel",
                        "agents_per_gpu": NA, "updates_per_step": U, "kernel": kernel,
+                       # batch 100 = six 16-row tiles + 4 rows: the MFMA kernels run their tail-of-four form
+                       "kernel_tail_of_four": bool(kernel == "mfma" and os.environ.get("RLC_NO_TAIL4", "0") != "1"),
                        "updates_timed_per_agent": U * args.steps, "updates_warmup_per_agent": U * args.warmup,
                        "per_gpu_value": NA * U * args.steps / dt_max,
                        "parallelism": ("independent seeds x%d per rank, x%d ranks SHARING the GPUs present (rehearsal, not a "
