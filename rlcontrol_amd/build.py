@@ -86,8 +86,10 @@ def audit_object(obj):
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         fb, co = os.path.join(tmp, "x.hipfb"), os.path.join(tmp, "x.co")
-        if subprocess.call([os.path.join(_LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, obj],
-                           stderr=subprocess.DEVNULL) != 0:
+        # (an explicit output file: with one positional argument llvm-objcopy rewrites `obj` in place, and the library
+        # then looks older than its objects)
+        if subprocess.call([os.path.join(_LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fb, obj,
+                            os.path.join(tmp, "x.o")], stderr=subprocess.DEVNULL) != 0:
             return {}                     # a host-only unit: no device code in it
         subprocess.check_call([os.path.join(_LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb,
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
